@@ -1,0 +1,65 @@
+import os
+import sys
+import importlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# Stated fp32 tolerances (reference fp32-vs-fp64 jitter is 4.4e-6 on a
+# pre-clamp output of std 0.165):
+PRE_ATOL, PRE_RTOL = 1e-4, 1e-3      # pre-clamp network output (normalised image units)
+IMG_ATOL = 0.05                      # final image, grey levels of 255
+STATE_ATOL, STATE_RTOL = 2e-5, 3e-4  # saved-state blob
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module("rerevst-code_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import rerevst_oracle
+    return rerevst_oracle
+
+
+@pytest.fixture(scope="session")
+def weights(pkg):
+    return pkg.synthetic_weights(0)
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def golden_inputs(pkg, g):
+    """Re-create the seeded inputs a golden case was generated from."""
+    sh, fh = tuple(int(v) for v in g["style_hw"]), tuple(int(v) for v in g["frame_hw"])
+    style = pkg.synth_style(*sh, kind="smooth", seed=7)
+    frames = [pkg.synth_frame(i, *fh, kind="smooth") for i in range(int(g["n_frames"]))]
+    return style, frames, [int(i) for i in g["sample_ids"]], int(g["transfer_id"])
+
+
+def assert_state_close(got, ref, what="state"):
+    err = np.abs(got - ref)
+    bound = STATE_ATOL + STATE_RTOL * np.abs(ref)
+    bad = err > bound
+    assert not bad.any(), "%s: %d entries out of tolerance, worst |d|=%.3e at ref=%.3e" % (
+        what, int(bad.sum()), float(err[bad].max()), float(ref[bad][np.argmax(err[bad])]))
+
+
+def assert_pre_close(got, ref, what="pre-clamp"):
+    err = np.abs(got - ref)
+    bound = PRE_ATOL + PRE_RTOL * np.abs(ref)
+    assert (err <= bound).all(), "%s: max|d|=%.3e (bound %.1e+%.1e|ref|)" % (what, float(err.max()), PRE_ATOL, PRE_RTOL)

@@ -1,0 +1,72 @@
+"""Pins the CPU oracle (oracle/rerevst_oracle.py) against the committed outputs of the
+unmodified reference network (tests/golden/*.npz, made by tests/golden/make_goldens.py)."""
+import numpy as np
+import pytest
+
+from conftest import (load_golden, golden_inputs, assert_state_close, assert_pre_close, IMG_ATOL)
+
+
+def _run(oracle, pkg, weights, g):
+    style, frames, ids, tid = golden_inputs(pkg, g)
+    o = oracle.Stylization(weights)
+    o.prepare_style(style)
+    o.clean()
+    for i in ids:
+        o.add(frames[i])          # unpadded (quirk Q6)
+    o.compute()
+    H, W = frames[0].shape[:2]
+    padded = oracle.reflect_pad(frames[tid], oracle.padded_size(H), oracle.padded_size(W))
+    return o, padded
+
+
+@pytest.mark.parametrize("case", ["global_a", "global_b"])
+def test_state_blob_matches_reference(case, oracle, pkg, weights):
+    g = load_golden(case)
+    o, _ = _run(oracle, pkg, weights, g)
+    assert_state_close(o.get_state(), g["state"])
+    s = o.F_style["map"].sum(axis=(0, 1, 2))
+    np.testing.assert_allclose(s, g["style_map_chansum"], rtol=1e-4, atol=1e-3)
+
+
+def test_transfer_matches_reference_full(oracle, pkg, weights):
+    g = load_golden("global_a")
+    o, padded = _run(oracle, pkg, weights, g)
+    assert_pre_close(o.transfer(padded, return_preclamp=True)[0], g["pre"])
+    out = o.transfer(padded)
+    assert out.dtype == np.float32 and out.shape == padded.shape
+    assert np.abs(out - g["out"]).max() <= IMG_ATOL
+
+
+def test_transfer_matches_reference_cropped_odd_sizes(oracle, pkg, weights):
+    g = load_golden("global_b")
+    o, padded = _run(oracle, pkg, weights, g)
+    H, W = (int(v) for v in g["frame_hw"])
+    pre = o.transfer(padded, return_preclamp=True)[0][64:64 + H, 64:64 + W]
+    assert_pre_close(pre, g["pre_crop"])
+    out = o.transfer(padded)[64:64 + H, 64:64 + W]
+    assert np.abs(out - g["out_crop"]).max() <= IMG_ATOL
+
+
+def test_set_state_roundtrip_and_uncomputed_error(oracle, pkg, weights):
+    g = load_golden("global_a")
+    o = oracle.Stylization(weights)
+    with pytest.raises(RuntimeError):
+        o.clean()
+        o.F_style = {"relu4_1": (0, 1)}
+        o.transfer(np.zeros((64, 64, 3), np.uint8))
+    o2 = oracle.Stylization(weights)
+    o2.set_state(g["state"])
+    np.testing.assert_array_equal(o2.get_state(), g["state"])
+    style, frames, ids, tid = golden_inputs(pkg, g)
+    padded = oracle.reflect_pad(frames[tid], 192, 192)
+    assert np.abs(o2.transfer(padded) - g["out"]).max() <= IMG_ATOL
+
+
+def test_driver_helpers(oracle):
+    assert [oracle.padded_size(n) for n in (256, 512, 1024, 436, 64)] == [384, 640, 1152, 576, 192]
+    assert oracle.sample_indices(300) == [8 * s for s in range(37)] + [299]
+    assert oracle.sample_indices(1) == [0]
+    img = np.arange(5 * 4 * 3, dtype=np.uint8).reshape(5, 4, 3)
+    p = oracle.reflect_pad(img, 192, 192)
+    assert p.shape == (192, 192, 3)
+    assert (p[63] == p[64]).all() and (p[:, 63] == p[:, 64]).all()   # edge-inclusive reflect
