@@ -1,0 +1,108 @@
+/*
+ * rerevst_hip.h — C ABI of librerevst_hip.so, the MI355X (gfx950) per-frame stylization
+ * path of ReReVST.
+ *
+ * Every entry point replaces one method of the reference's Python drop-in boundary,
+ * class `Stylization` in test/framework.py:56-118 (multi-style twin:
+ * "Multi-style Interpolation/stylization.py":42-100).  Plain pointers and sizes only; all
+ * image buffers are caller-owned.  A handle owns its device weights, workspace, saved
+ * state and one HIP stream; it is NOT thread-safe (the reference model is stateful and
+ * non-reentrant as well).  Multi-GPU = one handle per process per GPU.
+ *
+ * Return value: 0 on success, negative RRV_E_* otherwise; rrv_last_error() gives the text.
+ */
+#ifndef REREVST_HIP_H
+#define REREVST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rrv_ctx* rrv_handle;
+
+enum {
+    RRV_OK = 0,
+    RRV_E_ARG = -1,        /* bad argument / shape */
+    RRV_E_HIP = -2,        /* HIP runtime error */
+    RRV_E_WEIGHTS = -3,    /* unknown key, wrong shape, or weights incomplete */
+    RRV_E_STATE = -4,      /* transfer before compute()/set_state, compute with no frames, ... */
+    RRV_E_NOMEM = -5
+};
+
+/* Floats in the per-style shared-state blob: 11 norm layers x {mean,rstd,lo,hi}[C]
+ * (2368 channels), 6 dynamic filters [32][32], style (mean,std) for relu1_1..relu4_1
+ * (test/style_network_global.py:37-40,148,171,330).  Layout documented in DESIGN.md. */
+#define RRV_STATE_FLOATS 17536
+#define RRV_MAX_STYLES 8
+
+/* Stylization.__init__ (test/framework.py:57-78): picks the device and builds the model.
+ * `device` is the HIP device ordinal. */
+int rrv_create(int device, rrv_handle* out);
+int rrv_destroy(rrv_handle h);
+const char* rrv_last_error(rrv_handle h);
+
+/* model.load_state_dict(torch.load(checkpoint)) (test/framework.py:75): one call per
+ * state_dict key used by the inference path (Encoder.*, EncoderStyle.*, Decoder.*; the
+ * reference deletes Vgg19.* itself, style_network_global.py:467-469).  `data` is host
+ * fp32, OIHW for convolutions / [out,in] for FC, exactly as stored in the checkpoint;
+ * repacking to the kernel-native layout happens inside.  rrv_finalize_weights() checks
+ * the full key set is present (strict load) and uploads. */
+int rrv_load_weight(rrv_handle h, const char* key, const float* data, const int64_t* shape, int ndim);
+int rrv_finalize_weights(rrv_handle h);
+
+/* Stylization.prepare_style (test/framework.py:99-104; multi-style stylization.py:71-79).
+ * style: uint8 BGR HWC [Hs][Ws][3].  style_id in [0, RRV_MAX_STYLES). */
+int rrv_prepare_style(rrv_handle h, const uint8_t* style_bgr, int Hs, int Ws, int style_id);
+
+/* Stylization.clean (test/framework.py:93-95). */
+int rrv_clean(rrv_handle h);
+
+/* Stylization.add (test/framework.py:82-86): encode one sampled frame (uint8 BGR HWC,
+ * UNPADDED as the driver passes it, generate_real_video.py:139-143) and keep its
+ * relu4_1 feature.  All frames added between clean() and compute() must share H, W. */
+int rrv_add(rrv_handle h, const uint8_t* frame_bgr, int H, int W);
+
+/* Stylization.compute (test/framework.py:88-91): batched decoder pass over the added
+ * frames that records the saved statistics / dynamic filters for every prepared style. */
+int rrv_compute(rrv_handle h);
+
+/* The saved state of one style as a flat blob (what an RCCL broadcast ships to the other
+ * ranks, and what the golden fixtures compare).  n must be RRV_STATE_FLOATS. */
+int rrv_get_state(rrv_handle h, float* out, int n, int style_id);
+int rrv_set_state(rrv_handle h, const float* in, int n, int style_id);
+
+/* Stylization.transfer (test/framework.py:106-118): uint8 BGR HWC [H][W][3] in host
+ * memory -> float32 BGR HWC [H][W][3] in 0..255 in host memory.  H and W must be
+ * multiples of 8 (the reference driver pads to multiples of 64). */
+int rrv_transfer(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* out_bgr);
+
+/* Same computation on device-resident buffers (HBM in, HBM out), asynchronous on the
+ * handle's stream; rrv_sync() waits.  This is the entry the throughput bench times. */
+int rrv_transfer_device(rrv_handle h, const void* d_frame_bgr_u8, int H, int W, void* d_out_bgr_f32);
+
+/* Multi-style transfer (stylization.py:94-100 + style_network.py:432-460): every saved
+ * quantity is replaced by sum_s weight[s]*q_s before the same forward.  Device buffers. */
+int rrv_transfer_blend_device(rrv_handle h, const void* d_frame_bgr_u8, int H, int W,
+                              const float* style_weight, int n_styles, void* d_out_bgr_f32);
+
+/* Debug/parity taps: pre-clamp network output (normalised RGB, NHWC [H][W][3]) of the last
+ * transfer, copied to host. */
+int rrv_get_preclamp(rrv_handle h, float* out, int H, int W);
+
+int rrv_sync(rrv_handle h);
+
+/* Per-launch timing with HIP events recorded on the handle's own stream.
+ * rrv_profile_begin() clears the log and starts bracketing every kernel launch with
+ * events; rrv_profile_end() syncs and freezes the log.  Entry i: kernel name, elapsed ms,
+ * algorithmic FLOPs and algorithmic HBM bytes of that launch. */
+int rrv_profile_begin(rrv_handle h);
+int rrv_profile_end(rrv_handle h);
+int rrv_profile_count(rrv_handle h);
+int rrv_profile_entry(rrv_handle h, int i, const char** name, float* ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REREVST_HIP_H */

@@ -1,0 +1,34 @@
+"""Builds librerevst_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librerevst_hip.so")
+SOURCES = ["rerevst_hip.hip"]
+HEADERS = ["conv_mfma.h", "conv_thin.h", "prep_kernels.h", "../../include/rerevst_hip.h"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_lib(force=False, verbose=True, extra=()):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-Wno-unused-result", *extra,
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)

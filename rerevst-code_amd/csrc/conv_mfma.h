@@ -1,0 +1,264 @@
+// conv_mfma.h — implicit-GEMM 3x3 / 1x1 convolution on the gfx950 fp32 matrix cores.
+//
+// Replaces every >=32-channel nn.Conv2d call on the reference's per-frame path
+// (vgg19.features convs of Encoder, test/style_network_global.py:271-281; KernelFilter
+// down/up convs :181-187; ResidualBlock conv1/conv2/conv_shortcut :103-105) together with
+// the pointwise ops the reference runs as separate eager kernels after them: bias,
+// ReLU / LeakyReLU(0.2), MaxPool2d(2) (vgg cfg), F.interpolate(nearest, x2) in front of
+// the conv (:113), saved-statistics InstanceNorm.forward (:43-57), the residual adds
+// (:122, :217) and the AdaIN affine (:357-364).
+//
+// Data layout (HBM): activations are NHWC fp32 with a one-pixel ZERO ring:
+//   pixel (b,y,x) of a [B,H,W,C] tensor lives at ((b*(H+2) + y+1)*(W+2) + x+1)*C.
+// The ring supplies the conv zero padding, so the kernel has no bounds checks on loads;
+// stores are masked to y<H, x<W, which keeps the ring zero for the next layer.
+//
+// Tiling: one 256-thread workgroup (4 wave64) computes 128 output pixels (8 rows x 16
+// cols) x BN output channels.  An M-subtile of 32 pixels = 2 rows x 16 cols, so the
+// v_mfma_f32_32x32x2_f32 accumulator layout (lane: col = cout, regs: rows = pixels) puts
+// every 2x2 pooling window inside one lane.  K = taps x Cin is walked as
+// (16-channel chunk) x (tap): per chunk the (8+2)x(16+2) input halo tile is staged once in
+// LDS and re-used by all 9 taps (no im2col duplication); per (chunk,tap) a BN x 16 weight
+// block is staged.  Both are copied global->LDS with global_load_lds_dwordx4 (no VGPR
+// round trip), double-buffered, one barrier per (chunk,tap) step.
+//
+// LDS image: [pixel or cout row][16 floats], the four 16-byte pieces of a row XOR-swizzled
+// by (row>>2)&3 (applied on the per-lane SOURCE address, since the LDS-DMA destination is
+// lane-linear) so a ds_read_b128 of one k-group across 16 consecutive rows spreads over
+// all 64 banks.  k-mapping: one ds_read_b128 per operand feeds four MFMA k-steps — lane
+// half h reads channels 8g+4h+{0..3}; MFMA step s contracts {8g+s, 8g+4+s} (the order of
+// the K reduction is free).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum {
+    E_RELU = 1,      // max(v,0)
+    E_LRELU = 2,     // v>=0 ? v : 0.2v
+    E_NORM1 = 4,     // clamp((v-mean)*rstd, lo, hi) with saved stats n1
+    E_RES = 8,       // += residual at the same resolution
+    E_RES_UPS = 16,  // += residual stored at half resolution (nearest x2 of it)
+    E_NORM2 = 32,    // second saved-stat normalise + AdaIN affine (n2, sty)
+    E_POOL = 64      // 2x2 max pool before the store (output tensor is H/2 x W/2)
+};
+
+struct ConvP {
+    const float* in;   // input tensor (ring layout); dims Hi,Wi (half of H,W when UPS)
+    int Hi, Wi, Cin;
+    float* out;        // output tensor (ring layout); dims H,W (H/2,W/2 when E_POOL)
+    int H, W, Cout;    // convolution resolution and output channels
+    int B;
+    int in_bstride0;   // 1: input has B images; 0: every batch item reads image 0
+    const float* wpk;  // packed weights [Cout/BN][Cin/16][TAPS][BN][16 swizzled]
+    const float* bias; // [Cout]
+    const float* n1;   // [4][Cout]: mean, rstd, lo, hi
+    const float* res;  // residual tensor [B,Hr,Wr,Cout]
+    int Hr, Wr;
+    const float* n2;   // [4][Cout]
+    const float* sty;  // [2][Cout]: style mean, style std
+    int tiles_x, tiles_y;
+};
+
+template <int BN>
+struct WaveCfg {
+    static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
+    static constexpr int WAVES_M = 4 / WAVES_N;
+    static constexpr int WN_SUB = BN / 32 / WAVES_N;
+    static constexpr int WM_SUB = 4 / WAVES_M;
+};
+
+__device__ __forceinline__ void glds16(const float* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BN, int TAPS, bool UPS, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
+    using WC = WaveCfg<BN>;
+    constexpr int HWD = (TAPS == 1) ? 16 : (UPS ? 10 : 18);   // halo tile width  (pixels)
+    constexpr int HHT = (TAPS == 1) ? 8 : (UPS ? 6 : 10);     // halo tile height (pixels)
+    constexpr int NPIX = HHT * HWD;
+    constexpr int A_ITERS = (NPIX * 4 + 255) / 256;
+    constexpr int A_BYTES = A_ITERS * 256 * 16;
+    constexpr int B_PIECES = BN * 4;
+    constexpr int B_ITERS = (B_PIECES + 255) / 256;
+    constexpr int B_BYTES = BN * 64;
+    __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + 2 * B_BYTES];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave_m = wave % WC::WAVES_M, wave_n = wave / WC::WAVES_M;
+
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int n_tile = blockIdx.y;
+    const int y0 = ty * 8, x0 = tx * 16;
+    const int nchunks = p.Cin >> 4;
+
+    // ---- per-lane global source offsets of the A (halo) pieces; chunk base added later
+    const float* in_b = p.in + (size_t)(p.in_bstride0 ? b : 0) * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
+    const int ys = (TAPS == 1) ? y0 : (UPS ? (y0 >> 1) - 1 : y0 - 1);
+    const int xs = (TAPS == 1) ? x0 : (UPS ? (x0 >> 1) - 1 : x0 - 1);
+    int asrc[A_ITERS];
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+        const int e = it * 256 + tid;
+        int pp = e >> 2;
+        const int qq = e & 3;
+        if (pp >= NPIX) pp = 0;
+        const int hy = pp / HWD, hx = pp - hy * HWD;
+        asrc[it] = ((ys + hy + 1) * (p.Wi + 2) + (xs + hx + 1)) * p.Cin + 4 * (qq ^ ((pp >> 2) & 3));
+    }
+    const float* wsrc = p.wpk + (size_t)n_tile * nchunks * TAPS * (BN * 16) + tid * 4;
+
+    auto stage = [&](int chunk, int tap, int step) {
+        char* bdst = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
+        const float* wb = wsrc + (size_t)(chunk * TAPS + tap) * (BN * 16);
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) {
+            if (B_PIECES >= 256 || wave * 64 < B_PIECES)
+                glds16(wb + it * 1024, bdst + (it * 256 + wave * 64) * 16);
+        }
+        if (tap == 0) {
+            char* adst = smem + (chunk & 1) * A_BYTES;
+            const float* ab = in_b + chunk * 16;
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) glds16(ab + asrc[it], adst + (it * 256 + wave * 64) * 16);
+        }
+    };
+
+    // ---- per-lane LDS read offsets
+    const int r_ = l31 >> 4, c_ = l31 & 15;
+    int offB[WC::WN_SUB][2];
+#pragma unroll
+    for (int ns = 0; ns < WC::WN_SUB; ++ns) {
+        const int jj = (wave_n * WC::WN_SUB + ns) * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) offB[ns][g] = jj * 64 + ((((2 * g + h) ^ ((jj >> 2) & 3))) << 4);
+    }
+
+    f32x16 acc[WC::WM_SUB][WC::WN_SUB];
+#pragma unroll
+    for (int ms = 0; ms < WC::WM_SUB; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < WC::WN_SUB; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+
+    // ---- main loop: one barrier per (chunk, tap) step, next step's tiles in flight
+    stage(0, 0, 0);
+    int step = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const char* abuf = smem + (chunk & 1) * A_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap, ++step) {
+            __syncthreads();   // drains this wave's LDS-DMA (vmcnt 0) and publishes step's tiles
+            if (tap + 1 < TAPS)
+                stage(chunk, tap + 1, step + 1);
+            else if (chunk + 1 < nchunks)
+                stage(chunk + 1, 0, step + 1);
+            const char* bbuf = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            int offA[WC::WM_SUB];
+#pragma unroll
+            for (int ms = 0; ms < WC::WM_SUB; ++ms) {
+                const int msg = wave_m * WC::WM_SUB + ms;
+                int pp;
+                if (TAPS == 1)
+                    pp = (2 * msg + r_) * HWD + c_;
+                else if (UPS)
+                    pp = ((2 * msg + r_ + ky + 1) >> 1) * HWD + ((c_ + kx + 1) >> 1);
+                else
+                    pp = (2 * msg + r_ + ky) * HWD + c_ + kx;
+                offA[ms] = pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);   // g=0; g=1 flips bit 5
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                f32x4 a[WC::WM_SUB], bb[WC::WN_SUB];
+#pragma unroll
+                for (int ms = 0; ms < WC::WM_SUB; ++ms) a[ms] = *(const f32x4*)(abuf + (offA[ms] ^ (g << 5)));
+#pragma unroll
+                for (int ns = 0; ns < WC::WN_SUB; ++ns) bb[ns] = *(const f32x4*)(bbuf + offB[ns][g]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ms = 0; ms < WC::WM_SUB; ++ms)
+#pragma unroll
+                        for (int ns = 0; ns < WC::WN_SUB; ++ns)
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][s], bb[ns][s], acc[ms][ns], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- fused epilogue
+    const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
+    float* out_b = p.out + (size_t)b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
+    const float* res_b = nullptr;
+    if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
+#pragma unroll
+    for (int ns = 0; ns < WC::WN_SUB; ++ns) {
+        const int co = n_tile * BN + (wave_n * WC::WN_SUB + ns) * 32 + l31;
+        const float bias = p.bias[co];
+        float m1 = 0, r1 = 1, lo1 = 0, hi1 = 0, m2 = 0, r2 = 1, lo2 = 0, hi2 = 0, smean = 0, sstd = 1;
+        if (EPI & E_NORM1) {
+            m1 = p.n1[co]; r1 = p.n1[p.Cout + co]; lo1 = p.n1[2 * p.Cout + co]; hi1 = p.n1[3 * p.Cout + co];
+        }
+        if (EPI & E_NORM2) {
+            m2 = p.n2[co]; r2 = p.n2[p.Cout + co]; lo2 = p.n2[2 * p.Cout + co]; hi2 = p.n2[3 * p.Cout + co];
+            smean = p.sty[co]; sstd = p.sty[p.Cout + co];
+        }
+#pragma unroll
+        for (int ms = 0; ms < WC::WM_SUB; ++ms) {
+            const int msg = wave_m * WC::WM_SUB + ms;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // C layout: row i = (r&3) + 8*(r>>2) + 4h  ->  sub-row i>>4, col i&15
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int y = y0 + 2 * msg + (i >> 4), x = x0 + (i & 15);
+                float t = acc[ms][ns][r] + bias;
+                if (EPI & E_RELU) t = fmaxf(t, 0.f);
+                if (EPI & E_LRELU) t = (t >= 0.f) ? t : t * 0.2f;
+                if (EPI & E_NORM1) {
+                    t = (t - m1) * r1;
+                    t = fminf(hi1, fmaxf(lo1, t));
+                }
+                if (EPI & E_RES) {
+                    if (y < p.H && x < p.W) t += res_b[((y + 1) * (p.Wr + 2) + x + 1) * p.Cout + co];
+                }
+                if (EPI & E_RES_UPS) {
+                    if (y < p.H && x < p.W) t += res_b[(((y >> 1) + 1) * (p.Wr + 2) + (x >> 1) + 1) * p.Cout + co];
+                }
+                if (EPI & E_NORM2) {
+                    t = (t - m2) * r2;
+                    t = fminf(hi2, fmaxf(lo2, t));
+                    t = t * sstd + smean;
+                }
+                v[r] = t;
+            }
+            if (EPI & E_POOL) {
+                // 2x2 windows: rows = regs r, r+8 (sub-rows 0/1); cols = regs r, r+1
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const float m = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + 8], v[r + 9]));
+                    const int cx = (r & 3) + 8 * (r >> 2) + 4 * h;   // even column inside the tile
+                    const int y2 = (y0 >> 1) + msg, x2 = (x0 + cx) >> 1;
+                    if (y2 < Ho && x2 < Wo) out_b[((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co] = m;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int y = y0 + 2 * msg + (i >> 4), x = x0 + (i & 15);
+                    if (y < p.H && x < p.W) out_b[((y + 1) * (p.W + 2) + x + 1) * p.Cout + co] = v[r];
+                }
+            }
+        }
+    }
+}

@@ -1,0 +1,162 @@
+// conv_thin.h — the two HBM-bound ends of the per-frame path, on the vector ALUs.
+//
+// conv_first_k: uint8 BGR HWC frame -> [greyscale] -> ImageNet normalise -> conv3x3 3->64
+//   + bias + ReLU.  Fuses numpy2tensor/transform_image (test/framework.py:26-35),
+//   TransformerNet.RGB2Gray (test/style_network_global.py:487-497, quirk Q5) and
+//   vgg19.features[0:2].  Reads 3 B/pixel, writes 256 B/pixel.
+// conv_last_k: conv3x3 64->3 + bias (Decoder.slice1, :341,450) fused with
+//   transform_back_image/tensor2numpy (test/framework.py:39-49): *std+mean, clamp(0,1),
+//   *255, RGB->BGR, HWC float32.  Reads 256 B/pixel, writes 12 (+12) B/pixel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FirstP {
+    const uint8_t* img;   // [B][H][W][3] BGR
+    int H, W, B;
+    float* out;           // [B,H,W,64] ring layout
+    const float* w;       // [27][64]: row (ky*3+kx)*3 + c_rgb
+    const float* bias;    // [64]
+    int grey;             // 1: content frame (greyscaled), 0: style image (colour)
+    int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
+    __shared__ __attribute__((aligned(16))) float s_in[18 * 18 * 4];
+    __shared__ __attribute__((aligned(16))) float s_w[27 * 64];
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const uint8_t* img = p.img + (size_t)b * p.H * p.W * 3;
+
+    for (int i = tid; i < 27 * 64; i += 256) s_w[i] = p.w[i];
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    for (int i = tid; i < 18 * 18; i += 256) {
+        const int hy = i / 18, hx = i - hy * 18;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        float o[3] = {0.f, 0.f, 0.f};
+        if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+            const uint8_t* px = img + ((size_t)y * p.W + x) * 3;
+            float n[3];   // normalised, RGB order (framework.py:27,33-34)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) n[c] = ((float)px[2 - c] / 255.0f - mean[c]) / sd[c];
+            if (p.grey) {
+                float d[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = n[c] * sd[c] + mean[c];
+                const float g = d[2] * 0.299f + d[1] * 0.587f + d[0] * 0.114f;   // :493 (sic)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[c] = (g - mean[c]) / sd[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[c] = n[c];
+            }
+        }
+        *(f32x4*)&s_in[i * 4] = f32x4{o[0], o[1], o[2], 0.f};
+    }
+    __syncthreads();
+
+    const int q = tid & 15;      // output channels 4q..4q+3
+    const int prow = tid >> 4;   // pixel row inside the tile
+    f32x4 w[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) w[k] = *(const f32x4*)&s_w[k * 64 + q * 4];
+    const f32x4 bias = *(const f32x4*)&p.bias[q * 4];
+    float* out_b = p.out + (size_t)b * (size_t)(p.H + 2) * (p.W + 2) * 64;
+    const int y = y0 + prow;
+    for (int pc = 0; pc < 16; ++pc) {
+        f32x4 acc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 v = *(const f32x4*)&s_in[((prow + ky) * 18 + pc + kx) * 4];
+                const int k = (ky * 3 + kx) * 3;
+                acc += w[k] * v[0];
+                acc += w[k + 1] * v[1];
+                acc += w[k + 2] * v[2];
+            }
+        const int x = x0 + pc;
+        if (y < p.H && x < p.W) {
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e], 0.f);
+            *(f32x4*)&out_b[((size_t)(y + 1) * (p.W + 2) + x + 1) * 64 + q * 4] = r;
+        }
+    }
+}
+
+struct LastP {
+    const float* in;      // [1,H,W,64] ring layout
+    int H, W;
+    const float* w;       // [9][64][4]: tap, cin, cout(rgb, padded to 4)
+    const float* bias;    // [4]
+    float* out_img;       // [H][W][3] BGR float32 0..255
+    float* out_pre;       // optional [H][W][3] RGB pre-clamp (normalised units), may be null
+    int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
+    // 18x18 halo x 16 channels per stage, XOR-swizzled 16-byte pieces
+    __shared__ __attribute__((aligned(16))) float s_in[2][18 * 18 * 16];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int py = tid >> 4, px = tid & 15;
+
+    auto stage = [&](int chunk, int buf) {
+        for (int e = tid; e < 18 * 18 * 4; e += 256) {
+            const int pp = e >> 2, qq = e & 3;
+            const int hy = pp / 18, hx = pp - hy * 18;
+            const float* src = p.in + ((size_t)(y0 + hy) * (p.W + 2) + x0 + hx) * 64 + chunk * 16 + 4 * (qq ^ ((pp >> 2) & 3));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)((char*)&s_in[buf][0] + (e - (tid & 63)) * 16),
+                                             16, 0, 0);
+        }
+    };
+    float acc[3] = {0.f, 0.f, 0.f};
+    stage(0, 0);
+    for (int chunk = 0; chunk < 4; ++chunk) {
+        __syncthreads();
+        if (chunk + 1 < 4) stage(chunk + 1, (chunk + 1) & 1);
+        const char* buf = (const char*)&s_in[chunk & 1][0];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int pp = (py + ky) * 18 + px + kx;
+                const int sw = (pp >> 2) & 3;
+                const float* wt = p.w + ((ky * 3 + kx) * 64 + chunk * 16) * 4;   // wave-uniform -> scalar loads
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const f32x4 v = *(const f32x4*)(buf + pp * 64 + ((qq ^ sw) << 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float* w4 = wt + (qq * 4 + e) * 4;
+                        acc[0] += v[e] * w4[0];
+                        acc[1] += v[e] * w4[1];
+                        acc[2] += v[e] * w4[2];
+                    }
+                }
+            }
+    }
+    const int y = y0 + py, x = x0 + px;
+    if (y < p.H && x < p.W) {
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+        const size_t o = ((size_t)y * p.W + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = acc[c] + p.bias[c];
+            if (p.out_pre) p.out_pre[o + c] = t;
+            float im = t * sd[c] + mean[c];
+            im = fminf(fmaxf(im, 0.f), 1.f) * 255.f;
+            p.out_img[o + 2 - c] = im;   // RGB -> BGR
+        }
+    }
+}

@@ -1,0 +1,218 @@
+// prep_kernels.h — once-per-video / once-per-style kernels (not on the per-frame path):
+// per-channel statistics over (batch,H,W) (InstanceNorm.compute,
+// test/style_network_global.py:59-77; EncoderStyle.cal_mean_std :304-315), the pointwise
+// normalise / residual / AdaIN steps of Decoder.compute (:383-439), FilterPredictor's
+// 64->1024 FC (:161-172), the fold of the predicted 32x32 filters into the KernelFilter
+// convolutions, and the OIHW -> kernel-native weight repack.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- weight repack: OIHW -> [Cout/BN][Cin/16][TAPS][BN][16 floats, 16B pieces XOR (j>>2)&3]
+__global__ void pack_conv_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int taps, int BN) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // i indexes the destination
+        size_t r = i;
+        const int e = r & 3; r >>= 2;
+        const int qs = r & 3; r >>= 2;          // stored piece position
+        const int j = r % BN; r /= BN;
+        const int tap = r % taps; r /= taps;
+        const int nchunks = Cin >> 4;
+        const int chunk = r % nchunks; r /= nchunks;
+        const int n_tile = (int)r;
+        const int q = qs ^ ((j >> 2) & 3);      // logical piece
+        const int co = n_tile * BN + j, ci = chunk * 16 + q * 4 + e;
+        dst[i] = w[((size_t)co * Cin + ci) * taps + tap];
+    }
+}
+
+// conv_first weights: OIHW [64][3][3][3] -> [27][64] rows (ky*3+kx)*3 + c
+__global__ void pack_first_k(const float* __restrict__ w, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 27 * 64) {
+        const int co = i & 63, k = i >> 6, c = k % 3, tap = k / 3;
+        dst[i] = w[(co * 3 + c) * 9 + tap];
+    }
+}
+
+// conv_last weights: OIHW [3][64][3][3] -> [9][64][4]
+__global__ void pack_last_k(const float* __restrict__ w, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 9 * 64 * 4) {
+        const int co = i & 3, ci = (i >> 2) & 63, tap = i >> 8;
+        dst[i] = (co < 3) ? w[(co * 64 + ci) * 9 + tap] : 0.f;
+    }
+}
+
+// ---- folds of a dynamic 32x32 filter F (weight[out=i][in=j] = F[i][j], quirk Q2) -----
+// down' = F . Wd :  Wd'[o][ci][t] = sum_m F[o][m] Wd[m][ci][t],  bd'[o] = sum_m F[o][m] bd[m]
+__global__ void fold_down_k(const float* __restrict__ F, const float* __restrict__ Wd, const float* __restrict__ bd,
+                            float* __restrict__ Wout, float* __restrict__ bout, int CinT /* Cin*taps */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 32*CinT
+    if (i < 32 * CinT) {
+        const int o = i / CinT, k = i - o * CinT;
+        float s = 0.f;
+        for (int m = 0; m < 32; ++m) s += F[o * 32 + m] * Wd[(size_t)m * CinT + k];
+        Wout[i] = s;
+    }
+    if (i < 32) {
+        float s = 0.f;
+        for (int m = 0; m < 32; ++m) s += F[i * 32 + m] * bd[m];
+        bout[i] = s;
+    }
+}
+// up' = Wu . F :  Wu'[o][j][t] = sum_m Wu[o][m][t] F[m][j]
+__global__ void fold_up_k(const float* __restrict__ F, const float* __restrict__ Wu, float* __restrict__ Wout, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over Cout*32*9
+    if (i < Cout * 32 * 9) {
+        const int t = i % 9, j = (i / 9) & 31, o = i / (9 * 32);
+        float s = 0.f;
+        for (int m = 0; m < 32; ++m) s += Wu[((size_t)o * 32 + m) * 9 + t] * F[m * 32 + j];
+        Wout[i] = s;
+    }
+}
+
+// ---- FilterPredictor FC: out[1024] = W[1024][64] . [cmean(32), smean(32)] + b ---------
+__global__ void fc_filter_k(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ cmean,
+                            const float* __restrict__ smean, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 1024) {
+        float s = 0.f;
+        for (int k = 0; k < 32; ++k) s += W[i * 64 + k] * cmean[k];
+        for (int k = 0; k < 32; ++k) s += W[i * 64 + 32 + k] * smean[k];
+        out[i] = s + bias[i];
+    }
+}
+
+// ---- per-channel statistics over the valid pixels of a ring-layout tensor -------------
+// pass 0: sum;  pass 1 (needs mean): centred sum of squares, min, max.
+// part layout: [nblk][3][C] doubles.
+struct StatP {
+    const float* x;
+    int B, H, W, C;
+    const float* mean;   // pass 1
+    double* part;
+    int pass;
+    int pix_per_blk;
+};
+
+__global__ __launch_bounds__(256) void chan_stat_k(const StatP p) {
+    __shared__ double s_red[3][256];
+    const int tid = threadIdx.x;
+    const int Cb = p.C < 256 ? p.C : 256;
+    const int nsub = 256 / Cb;
+    const int cl = tid % Cb, sub = tid / Cb;
+    const long npix = (long)p.B * p.H * p.W;
+    const long p0 = (long)blockIdx.x * p.pix_per_blk;
+    long p1 = p0 + p.pix_per_blk;
+    if (p1 > npix) p1 = npix;
+    for (int cg = 0; cg < p.C; cg += Cb) {
+        const int c = cg + cl;
+        double s = 0.0;
+        float mn = 3.4e38f, mx = -3.4e38f;
+        const float m = p.pass ? p.mean[c] : 0.f;
+        for (long q = p0 + sub; q < p1; q += nsub) {
+            const int x = (int)(q % p.W);
+            const long r = q / p.W;
+            const int y = (int)(r % p.H);
+            const long b = r / p.H;
+            const float v = p.x[((b * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * (long)p.C + c];
+            if (p.pass) {
+                const float d = v - m;
+                s += (double)(d * d);
+                mn = fminf(mn, v);
+                mx = fmaxf(mx, v);
+            } else {
+                s += (double)v;
+            }
+        }
+        s_red[0][tid] = s; s_red[1][tid] = mn; s_red[2][tid] = mx;
+        __syncthreads();
+        if (sub == 0) {
+            for (int k = 1; k < nsub; ++k) {
+                s += s_red[0][k * Cb + cl];
+                mn = fminf(mn, (float)s_red[1][k * Cb + cl]);
+                mx = fmaxf(mx, (float)s_red[2][k * Cb + cl]);
+            }
+            double* o = p.part + (size_t)blockIdx.x * 3 * p.C;
+            o[c] = s; o[p.C + c] = mn; o[2 * p.C + c] = mx;
+        }
+        __syncthreads();
+    }
+}
+
+// final reduce.  mode 0: mean only -> out[c]
+//               mode 1: content stats -> n[4][C] = mean, rsqrt(ss/N + 1e-8), (min-mean)*rstd, (max-mean)*rstd
+//               mode 2: style stats   -> sty[2][C] = mean, sqrt(ss/(N-1) + 1e-5)
+__global__ void chan_final_k(const double* __restrict__ part, int nblk, int C, double N, int mode,
+                             const float* __restrict__ mean_in, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    float mn = 3.4e38f, mx = -3.4e38f;
+    for (int k = 0; k < nblk; ++k) {
+        const double* o = part + (size_t)k * 3 * C;
+        s += o[c];
+        mn = fminf(mn, (float)o[C + c]);
+        mx = fmaxf(mx, (float)o[2 * C + c]);
+    }
+    if (mode == 0) {
+        out[c] = (float)(s / N);
+    } else if (mode == 1) {
+        const float m = mean_in[c];
+        const float var = (float)(s / N) + 1e-8f;
+        const float r = 1.0f / sqrtf(var);
+        out[c] = m; out[C + c] = r; out[2 * C + c] = (mn - m) * r; out[3 * C + c] = (mx - m) * r;
+    } else {
+        const float var = (float)(s / (N - 1.0)) + 1e-5f;
+        out[c] = mean_in[c]; out[C + c] = sqrtf(var);
+    }
+}
+
+// ---- pointwise step of the preparation pass (valid pixels only, ring preserved) -------
+struct PointP {
+    const float* x; float* y;      // y may alias x
+    int B, H, W, C;
+    const float* mean; const float* scale;   // normalise: (v-mean)*scale, or /scale when div
+    int div;
+    const float* res; int res_mode;          // 0 none, 1 same-res image 0 broadcast, 2 half-res per batch
+    int Hr, Wr;
+    const float* smean; const float* sstd;   // affine after
+};
+__global__ void pointwise_k(const PointP p) {
+    const long total = (long)p.B * p.H * p.W * (p.C >> 2);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (p.C >> 2)) * 4;
+        long r = i / (p.C >> 2);
+        const int x = (int)(r % p.W); r /= p.W;
+        const int y = (int)(r % p.H);
+        const long b = r / p.H;
+        const long idx = ((b * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * (long)p.C + c4;
+        float4 v = *(const float4*)(p.x + idx);
+        float* pv = &v.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = pv[e];
+            if (p.mean) t = p.div ? (t - p.mean[c4 + e]) / p.scale[c4 + e] : (t - p.mean[c4 + e]) * p.scale[c4 + e];
+            if (p.res_mode == 1) t += p.res[((long)(y + 1) * (p.Wr + 2) + x + 1) * p.C + c4 + e];
+            if (p.res_mode == 2)
+                t += p.res[((b * (p.Hr + 2) + (y >> 1) + 1) * (p.Wr + 2) + (x >> 1) + 1) * (long)p.C + c4 + e];
+            if (p.smean) t = t * p.sstd[c4 + e] + p.smean[c4 + e];
+            pv[e] = t;
+        }
+        *(float4*)(p.y + idx) = v;
+    }
+}
+
+// blended state for multi-style interpolation: out = sum_s w[s] * state_s
+// ("Multi-style Interpolation/style_network.py":41-45,137-138,354-356)
+struct BlendP { const float* st[8]; float w[8]; int n; float* out; int count; };
+__global__ void blend_state_k(const BlendP p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.count) {
+        float s = 0.f;
+        for (int k = 0; k < p.n; ++k) s += p.w[k] * p.st[k][i];
+        p.out[i] = s;
+    }
+}

@@ -1,0 +1,832 @@
+// rerevst_hip.hip — host side of librerevst_hip.so: the C ABI declared in
+// include/rerevst_hip.h, weight upload/repack, the per-frame launch sequence
+// (Stylization.transfer, test/framework.py:106-118) and the preparation passes
+// (prepare_style / add / compute, test/framework.py:82-104).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rerevst_hip.h"
+#include "conv_mfma.h"
+#include "conv_thin.h"
+#include "prep_kernels.h"
+
+namespace {
+
+// ---- state blob layout (must match oracle/rerevst_oracle.py and DESIGN.md) -------------
+const int NORM_CH[11] = {512, 512, 256, 128, 64, 256, 256, 128, 128, 64, 64};
+enum { N_DEC0 = 0, N_DEC1, N_DEC2, N_DEC3, N_DEC4, N_S4N1, N_S4N2, N_S3N1, N_S3N2, N_S2N1, N_S2N2 };
+const int STYLE_CH[4] = {64, 128, 256, 512};
+struct StateLayout {
+    int norm[11], filt[6], sty[4];
+    StateLayout() {
+        int o = 0;
+        for (int i = 0; i < 11; ++i) { norm[i] = o; o += 4 * NORM_CH[i]; }
+        for (int i = 0; i < 6; ++i) { filt[i] = o; o += 1024; }
+        for (int i = 0; i < 4; ++i) { sty[i] = o; o += 2 * STYLE_CH[i]; }
+    }
+};
+const StateLayout SL;
+
+struct Tens {
+    float* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t img_floats() const { return (size_t)(H + 2) * (W + 2) * C; }
+};
+
+struct ConvW {           // one convolution's device weights
+    float* raw = nullptr;    // OIHW as in the checkpoint
+    float* pk = nullptr;     // kernel-native packed
+    float* bias = nullptr;   // [Cout] (zeros for bias-free convs)
+    int Cout = 0, Cin = 0, taps = 0, BN = 0;
+};
+
+struct ProfEntry { const char* name; hipEvent_t e0, e1; double flops, bytes; float ms; };
+
+// VGG conv indices and (cin,cout)
+const int VGG_IDX[9] = {0, 2, 5, 7, 10, 12, 14, 16, 19};
+const int VGG_CIN[9] = {3, 64, 64, 128, 128, 256, 256, 256, 256};
+const int VGG_COUT[9] = {64, 64, 128, 128, 256, 256, 256, 256, 512};
+const int STYLE_SLICE[9] = {1, 2, 2, 3, 3, 4, 4, 4, 4};
+
+struct EncPlan {   // encoder activations for one (B=1, H, W)
+    int H = 0, W = 0;
+    Tens c11, p1, c21, p2, c31, c32, c33, p3, c41;
+};
+struct DecPlan {   // per-frame decoder activations for one (H, W) of the FRAME
+    int H = 0, W = 0;
+    Tens d, f1, f2, f3, xs4, a4, o4, xs3, a3, o3, xs2, a2, o2;
+    float* pre = nullptr;   // [H][W][3] pre-clamp tap
+};
+
+struct StyleState {
+    bool prepared = false, computed = false;
+    float* blob = nullptr;           // RRV_STATE_FLOATS on device
+    Tens map;                        // relu4_1 style map
+};
+
+}  // namespace
+
+struct rrv_ctx {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, std::vector<float>> hostw;
+    std::map<std::string, std::vector<int64_t>> hostshape;
+    bool finalized = false;
+    std::map<std::string, ConvW> conv;         // keyed by state_dict prefix (without .weight)
+    float *first_w[2] = {nullptr, nullptr}, *first_b[2] = {nullptr, nullptr};   // 0: Encoder, 1: EncoderStyle
+    float *last_w = nullptr, *last_b = nullptr;
+    float* fc_w[6] = {nullptr}; float* fc_b[6] = {nullptr};
+    float* zero_bias = nullptr;                // 512 zeros
+    // folded KernelFilter weights for the ACTIVE state
+    ConvW fold_down[3], fold_up[3];
+    float* fold_tmp = nullptr;                 // OIHW scratch for folds (512*32*9 floats)
+    StyleState styles[RRV_MAX_STYLES];
+    float* active = nullptr;                   // state the per-frame path reads (blob layout)
+    int active_src = -1;                       // style id whose state is folded (-2: blend)
+    EncPlan enc_frame, enc_add, enc_style;
+    DecPlan dec;
+    std::vector<float*> patches;               // relu4_1 features of added frames (ring layout images)
+    int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
+    uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
+    float* d_outf = nullptr; size_t d_outf_cap = 0;
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            char _b[512];                                                                         \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            h->err = _b;                                                                          \
+            return RRV_E_HIP;                                                                     \
+        }                                                                                         \
+    } while (0)
+#define RCHK(expr) do { int _r = (expr); if (_r != RRV_OK) return _r; } while (0)
+
+int fail(rrv_handle h, int code, const std::string& msg) { h->err = msg; return code; }
+
+int dalloc(rrv_handle h, float** p, size_t floats, bool zero = true) {
+    HIPCHK(hipMalloc((void**)p, floats * sizeof(float)));
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, floats * sizeof(float), h->stream));
+    return RRV_OK;
+}
+
+// ring-layout tensor; slack rows keep tile-overrun halo reads inside the allocation
+int talloc(rrv_handle h, Tens* t, int B, int H, int W, int C) {
+    if (t->p) { (void)hipFree(t->p); t->p = nullptr; }
+    t->B = B; t->H = H; t->W = W; t->C = C;
+    const size_t slack = (size_t)20 * (W + 2 + 20) * C;
+    return dalloc(h, &t->p, (size_t)B * t->img_floats() + slack, true);
+}
+void tfree(Tens* t) { if (t->p) (void)hipFree(t->p); t->p = nullptr; }
+
+template <typename F>
+int launch(rrv_handle h, const char* name, double flops, double bytes, F&& f) {
+    if (h->profiling) {
+        ProfEntry e{name, nullptr, nullptr, flops, bytes, 0.f};
+        HIPCHK(hipEventCreate(&e.e0)); HIPCHK(hipEventCreate(&e.e1));
+        HIPCHK(hipEventRecord(e.e0, h->stream));
+        f();
+        HIPCHK(hipEventRecord(e.e1, h->stream));
+        h->prof.push_back(e);
+    } else {
+        f();
+    }
+    HIPCHK(hipGetLastError());
+    return RRV_OK;
+}
+
+// ---- convolution dispatch -------------------------------------------------------------
+struct ConvCall {
+    const Tens* in; Tens* out; const ConvW* w;
+    int H, W;                 // convolution resolution
+    bool ups = false; int epi = 0;
+    const float* n1 = nullptr; const Tens* res = nullptr; const float* n2 = nullptr; const float* sty = nullptr;
+    int B = 1;
+};
+
+template <int BN, int TAPS, bool UPS, int EPI>
+void conv_launch(const ConvP& p, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, UPS, EPI>), grid, dim3(256), 0, s, p);
+}
+
+typedef void (*ConvFn)(const ConvP&, dim3, hipStream_t);
+struct ConvKey { int BN, TAPS, UPS, EPI; ConvFn fn; const char* name; };
+#define CK(BN, TAPS, UPS, EPI) {BN, TAPS, UPS, EPI, &conv_launch<BN, TAPS, UPS, EPI>, "conv_mfma<" #BN "," #TAPS "," #UPS "," #EPI ">"}
+const ConvKey CONV_TABLE[] = {
+    // encoder
+    CK(64, 9, 0, E_RELU | E_POOL), CK(128, 9, 0, E_RELU), CK(128, 9, 0, E_RELU | E_POOL),
+    CK(128, 9, 0, E_RELU | E_NORM1), CK(64, 9, 0, E_RELU),
+    // KernelFilter (folded dynamic filters)
+    CK(32, 9, 0, E_LRELU), CK(128, 9, 0, E_RES), CK(128, 9, 0, E_RES | E_NORM2),
+    // residual blocks, per-frame
+    CK(128, 1, 0, 0), CK(64, 1, 0, 0),
+    CK(128, 9, 1, E_LRELU | E_NORM1), CK(64, 9, 1, E_LRELU | E_NORM1),
+    CK(128, 9, 0, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), CK(64, 9, 0, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2),
+    // preparation pass (raw outputs, statistics taken afterwards)
+    CK(32, 9, 0, 0), CK(128, 9, 0, 0), CK(128, 9, 1, E_LRELU), CK(64, 9, 1, E_LRELU),
+    CK(128, 9, 0, E_LRELU), CK(64, 9, 0, E_LRELU),
+};
+
+int conv(rrv_handle h, const ConvCall& c) {
+    const ConvW& w = *c.w;
+    const ConvKey* k = nullptr;
+    for (const ConvKey& e : CONV_TABLE)
+        if (e.BN == w.BN && e.TAPS == w.taps && e.UPS == (int)c.ups && e.EPI == c.epi) { k = &e; break; }
+    if (!k) {
+        char b[128];
+        snprintf(b, sizeof b, "no conv kernel for BN=%d taps=%d ups=%d epi=%d", w.BN, w.taps, (int)c.ups, c.epi);
+        return fail(h, RRV_E_ARG, b);
+    }
+    ConvP p{};
+    p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W; p.Cin = w.Cin;
+    p.out = c.out->p; p.H = c.H; p.W = c.W; p.Cout = w.Cout; p.B = c.B;
+    p.in_bstride0 = 1;
+    p.wpk = w.pk; p.bias = w.bias; p.n1 = c.n1; p.n2 = c.n2; p.sty = c.sty;
+    if (c.res) { p.res = c.res->p; p.Hr = c.res->H; p.Wr = c.res->W; }
+    p.tiles_x = (c.W + 15) / 16; p.tiles_y = (c.H + 7) / 8;
+    if (c.in->C != w.Cin || c.out->C != w.Cout) return fail(h, RRV_E_ARG, "conv: channel mismatch");
+    const int eh = c.ups ? c.H / 2 : c.H, ew = c.ups ? c.W / 2 : c.W;
+    if (c.in->H != eh || c.in->W != ew) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");
+    const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
+    if (c.out->H != oh || c.out->W != ow) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B), (unsigned)(w.Cout / w.BN));
+    const double px = (double)c.B * c.H * c.W;
+    const double flops = 2.0 * px * w.Cout * w.Cin * w.taps;
+    const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * w.Cin + (double)c.B * oh * ow * w.Cout +
+                                (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps);
+    hipStream_t s = h->stream;
+    ConvFn fn = k->fn;
+    return launch(h, k->name, flops, bytes, [&] { fn(p, grid, s); });
+}
+
+// ---- weights ----------------------------------------------------------------------------
+int upload(rrv_handle h, const std::string& key, float** dst, size_t expect) {
+    auto it = h->hostw.find(key);
+    if (it == h->hostw.end()) return fail(h, RRV_E_WEIGHTS, "missing weight " + key);
+    if (it->second.size() != expect) return fail(h, RRV_E_WEIGHTS, "wrong size for " + key);
+    RCHK(dalloc(h, dst, expect, false));
+    HIPCHK(hipMemcpyAsync(*dst, it->second.data(), expect * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    return RRV_OK;
+}
+
+int pack(rrv_handle h, ConvW& w) {
+    if (!w.pk) RCHK(dalloc(h, &w.pk, (size_t)w.Cout * w.Cin * w.taps, false));
+    const size_t total = (size_t)w.Cout * w.Cin * w.taps;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv_k, dim3(blocks), dim3(256), 0, h->stream, (const float*)w.raw, w.pk, w.Cout, w.Cin, w.taps, w.BN);
+    HIPCHK(hipGetLastError());
+    return RRV_OK;
+}
+
+int bn_for(int cout) { return cout >= 128 ? 128 : (cout >= 64 ? 64 : 32); }
+
+int make_conv(rrv_handle h, const std::string& prefix, int cout, int cin, int taps, bool has_bias, bool do_pack = true) {
+    ConvW w;
+    w.Cout = cout; w.Cin = cin; w.taps = taps; w.BN = bn_for(cout);
+    RCHK(upload(h, prefix + ".weight", &w.raw, (size_t)cout * cin * taps));
+    if (has_bias) RCHK(upload(h, prefix + ".bias", &w.bias, (size_t)cout));
+    else w.bias = h->zero_bias;
+    if (do_pack) RCHK(pack(h, w));
+    h->conv[prefix] = w;
+    return RRV_OK;
+}
+
+// ---- statistics helpers -----------------------------------------------------------------
+// mode 0: out[C] = mean;  mode 1: out = norm params [4][C];  mode 2: out = style (mean,std) [2][C]
+int chan_stats(rrv_handle h, const Tens& t, int mode, float* out) {
+    const long npix = (long)t.B * t.H * t.W;
+    int nblk = (int)((npix + 1023) / 1024);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    const int ppb = (int)((npix + nblk - 1) / nblk);
+    double* part = nullptr;
+    float* mean = nullptr;
+    HIPCHK(hipMalloc((void**)&part, (size_t)nblk * 3 * t.C * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&mean, (size_t)t.C * sizeof(float)));
+    StatP sp{t.p, t.B, t.H, t.W, t.C, nullptr, part, 0, ppb};
+    const int fb = (t.C + 63) / 64;
+    RCHK(launch(h, "chan_stat", 0, 0, [&] { hipLaunchKernelGGL(chan_stat_k, dim3(nblk), dim3(256), 0, h->stream, sp); }));
+    RCHK(launch(h, "chan_final", 0, 0, [&] {
+        hipLaunchKernelGGL(chan_final_k, dim3(fb), dim3(64), 0, h->stream, (const double*)part, nblk, t.C, (double)npix, 0,
+                           (const float*)nullptr, mode == 0 ? out : mean);
+    }));
+    if (mode != 0) {
+        sp.pass = 1; sp.mean = mean;
+        RCHK(launch(h, "chan_stat", 0, 0, [&] { hipLaunchKernelGGL(chan_stat_k, dim3(nblk), dim3(256), 0, h->stream, sp); }));
+        RCHK(launch(h, "chan_final", 0, 0, [&] {
+            hipLaunchKernelGGL(chan_final_k, dim3(fb), dim3(64), 0, h->stream, (const double*)part, nblk, t.C, (double)npix, mode,
+                               (const float*)mean, out);
+        }));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(part); (void)hipFree(mean);
+    return RRV_OK;
+}
+
+int pointwise(rrv_handle h, const Tens& x, Tens& y, const float* mean, const float* scale, bool div, const Tens* res,
+              int res_mode, const float* smean, const float* sstd) {
+    PointP p{x.p, y.p, x.B, x.H, x.W, x.C, mean, scale, div ? 1 : 0, res ? res->p : nullptr, res_mode,
+             res ? res->H : 0, res ? res->W : 0, smean, sstd};
+    const long total = (long)x.B * x.H * x.W * (x.C / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    return launch(h, "pointwise", 0, 0, [&] { hipLaunchKernelGGL(pointwise_k, dim3(blocks), dim3(256), 0, h->stream, p); });
+}
+
+// ---- folded KernelFilter weights for a state blob ------------------------------------------
+int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
+    char pre[64];
+    snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
+    const ConvW& wd = h->conv[std::string(pre) + ".down_sample.0"];
+    const ConvW& wu = h->conv[std::string(pre) + ".upsample.0"];
+    ConvW& fd = h->fold_down[f];
+    ConvW& fu = h->fold_up[f];
+    const float* F1 = blob + SL.filt[2 * f];
+    const float* F2 = blob + SL.filt[2 * f + 1];
+    hipLaunchKernelGGL(fold_down_k, dim3((32 * 512 * 9 + 255) / 256), dim3(256), 0, h->stream, F1, (const float*)wd.raw,
+                       (const float*)wd.bias, fd.raw, fd.bias, 512 * 9);
+    HIPCHK(hipGetLastError());
+    RCHK(pack(h, fd));
+    hipLaunchKernelGGL(fold_up_k, dim3((512 * 32 * 9 + 255) / 256), dim3(256), 0, h->stream, F2, (const float*)wu.raw, fu.raw, 512);
+    HIPCHK(hipGetLastError());
+    RCHK(pack(h, fu));
+    return RRV_OK;
+}
+
+int activate_state(rrv_handle h, int style_id) {
+    if (h->active_src == style_id) return RRV_OK;
+    StyleState& s = h->styles[style_id];
+    HIPCHK(hipMemcpyAsync(h->active, s.blob, RRV_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
+    h->active_src = style_id;
+    return RRV_OK;
+}
+
+// ---- encoder ----------------------------------------------------------------------------
+int enc_plan(rrv_handle h, EncPlan& e, int H, int W) {
+    if (e.H == H && e.W == W && e.c11.p) return RRV_OK;
+    e.H = H; e.W = W;
+    const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
+    RCHK(talloc(h, &e.c11, 1, H, W, 64));
+    RCHK(talloc(h, &e.p1, 1, H2, W2, 64));
+    RCHK(talloc(h, &e.c21, 1, H2, W2, 128));
+    RCHK(talloc(h, &e.p2, 1, H4, W4, 128));
+    RCHK(talloc(h, &e.c31, 1, H4, W4, 256));
+    RCHK(talloc(h, &e.c32, 1, H4, W4, 256));
+    RCHK(talloc(h, &e.c33, 1, H4, W4, 256));
+    RCHK(talloc(h, &e.p3, 1, H8, W8, 256));
+    RCHK(talloc(h, &e.c41, 1, H8, W8, 512));
+    return RRV_OK;
+}
+
+// vgg19.features[0:21] on a device-resident uint8 BGR image.  which: 0 Encoder (grey), 1 EncoderStyle (colour).
+// norm0 != nullptr fuses Decoder.norm[0] into the last conv (per-frame path).
+int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0) {
+    const int H = e.H, W = e.W;
+    FirstP fp{d_img, H, W, 1, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16};
+    RCHK(launch(h, "conv_first", 2.0 * H * W * 27 * 64, 3.0 * H * W + 256.0 * H * W, [&] {
+        hipLaunchKernelGGL(conv_first_k, dim3(fp.tiles_x * fp.tiles_y), dim3(256), 0, h->stream, fp);
+    }));
+    auto W_ = [&](int i) -> const ConvW* {
+        char k[64];
+        if (which == 0) snprintf(k, sizeof k, "Encoder.slice.%d", VGG_IDX[i]);
+        else snprintf(k, sizeof k, "EncoderStyle.slice%d.%d", STYLE_SLICE[i], VGG_IDX[i]);
+        return &h->conv[k];
+    };
+    ConvCall c;
+    c = ConvCall{&e.c11, &e.p1, W_(1), H, W}; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
+    c = ConvCall{&e.p1, &e.c21, W_(2), H / 2, W / 2}; c.epi = E_RELU; RCHK(conv(h, c));
+    c = ConvCall{&e.c21, &e.p2, W_(3), H / 2, W / 2}; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
+    c = ConvCall{&e.p2, &e.c31, W_(4), e.p2.H, e.p2.W}; c.epi = E_RELU; RCHK(conv(h, c));
+    c = ConvCall{&e.c31, &e.c32, W_(5), e.p2.H, e.p2.W}; c.epi = E_RELU; RCHK(conv(h, c));
+    c = ConvCall{&e.c32, &e.c33, W_(6), e.p2.H, e.p2.W}; c.epi = E_RELU; RCHK(conv(h, c));
+    c = ConvCall{&e.c33, &e.p3, W_(7), e.p2.H, e.p2.W}; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
+    c = ConvCall{&e.p3, &e.c41, W_(8), e.p3.H, e.p3.W}; c.epi = E_RELU | (norm0 ? E_NORM1 : 0); c.n1 = norm0; RCHK(conv(h, c));
+    return RRV_OK;
+}
+
+int ensure_u8(rrv_handle h, size_t bytes) {
+    if (h->d_u8_cap >= bytes) return RRV_OK;
+    if (h->d_u8) (void)hipFree(h->d_u8);
+    HIPCHK(hipMalloc((void**)&h->d_u8, bytes));
+    h->d_u8_cap = bytes;
+    return RRV_OK;
+}
+
+// ---- per-frame decoder --------------------------------------------------------------------
+int dec_plan(rrv_handle h, DecPlan& d, int H, int W) {
+    if (d.H == H && d.W == W && d.d.p) return RRV_OK;
+    d.H = H; d.W = W;
+    const int H8 = H / 8, W8 = W / 8, H4 = H / 4, W4 = W / 4, H2 = H / 2, W2 = W / 2;
+    RCHK(talloc(h, &d.d, 1, H8, W8, 32));
+    RCHK(talloc(h, &d.f1, 1, H8, W8, 512));
+    RCHK(talloc(h, &d.f2, 1, H8, W8, 512));
+    RCHK(talloc(h, &d.f3, 1, H8, W8, 512));
+    RCHK(talloc(h, &d.xs4, 1, H8, W8, 256));
+    RCHK(talloc(h, &d.a4, 1, H4, W4, 256));
+    RCHK(talloc(h, &d.o4, 1, H4, W4, 256));
+    RCHK(talloc(h, &d.xs3, 1, H4, W4, 128));
+    RCHK(talloc(h, &d.a3, 1, H2, W2, 128));
+    RCHK(talloc(h, &d.o3, 1, H2, W2, 128));
+    RCHK(talloc(h, &d.xs2, 1, H2, W2, 64));
+    RCHK(talloc(h, &d.a2, 1, H, W, 64));
+    RCHK(talloc(h, &d.o2, 1, H, W, 64));
+    if (d.pre) (void)hipFree(d.pre);
+    RCHK(dalloc(h, &d.pre, (size_t)H * W * 3, true));
+    return RRV_OK;
+}
+
+int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens& a, Tens& o, int n1, int n2, int nada, int sty) {
+    const float* st = h->active;
+    const std::string p = std::string("Decoder.") + blk;
+    ConvCall c;
+    c = ConvCall{&in, &xs, &h->conv[p + ".conv_shortcut"], in.H, in.W}; RCHK(conv(h, c));   // up(conv1x1(x)) == conv1x1(up(x))
+    c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1]; RCHK(conv(h, c));
+    c = ConvCall{&a, &o, &h->conv[p + ".conv2"], a.H, a.W};
+    c.epi = E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2; c.n1 = st + SL.norm[n2]; c.res = &xs; c.n2 = st + SL.norm[nada]; c.sty = st + SL.sty[sty];
+    RCHK(conv(h, c));
+    return RRV_OK;
+}
+
+int transfer_device(rrv_handle h, const uint8_t* d_in, int H, int W, float* d_out) {
+    if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
+    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
+    if (h->active_src == -1) return fail(h, RRV_E_STATE, "state not computed: call compute() (or set_state) before transfer()");
+    RCHK(enc_plan(h, h->enc_frame, H, W));
+    RCHK(dec_plan(h, h->dec, H, W));
+    DecPlan& d = h->dec;
+    EncPlan& e = h->enc_frame;
+    const float* st = h->active;
+    RCHK(run_encoder(h, e, d_in, 0, st + SL.norm[N_DEC0]));
+    const Tens* cur = &e.c41;
+    Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
+    for (int f = 0; f < 3; ++f) {
+        ConvCall c{cur, &d.d, &h->fold_down[f], cur->H, cur->W}; c.epi = E_LRELU; RCHK(conv(h, c));
+        ConvCall u{&d.d, fo[f], &h->fold_up[f], cur->H, cur->W};
+        u.epi = E_RES | (f == 2 ? E_NORM2 : 0); u.res = cur;
+        if (f == 2) { u.n2 = st + SL.norm[N_DEC1]; u.sty = st + SL.sty[3]; }
+        RCHK(conv(h, u));
+        cur = fo[f];
+    }
+    RCHK(resblock_frame(h, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2));
+    RCHK(resblock_frame(h, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1));
+    RCHK(resblock_frame(h, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0));
+    LastP lp{d.o2.p, H, W, h->last_w, h->last_b, d_out, d.pre, (W + 15) / 16, (H + 15) / 16};
+    RCHK(launch(h, "conv_last", 2.0 * H * W * 576 * 3, 256.0 * H * W + 12.0 * H * W, [&] {
+        hipLaunchKernelGGL(conv_last_k, dim3(lp.tiles_x * lp.tiles_y), dim3(256), 0, h->stream, lp);
+    }));
+    return RRV_OK;
+}
+
+// ---- preparation: Decoder.compute for one style ---------------------------------------------
+int compute_style(rrv_handle h, int sid, const Tens& content) {
+    StyleState& S = h->styles[sid];
+    float* st = S.blob;
+    const int B = content.B, hh = content.H, ww = content.W;
+    Tens cn, nxt, sn, t32, ts32, d32, u, xs, a, o;
+    float *cmean = nullptr, *smean = nullptr;
+    RCHK(dalloc(h, &cmean, 32)); RCHK(dalloc(h, &smean, 32));
+    int rc = RRV_OK;
+    auto body = [&]() -> int {
+        // norm[0].compute on the batch (style_network_global.py:396)
+        RCHK(chan_stats(h, content, 1, st + SL.norm[N_DEC0]));
+        RCHK(talloc(h, &cn, B, hh, ww, 512));
+        RCHK(talloc(h, &nxt, B, hh, ww, 512));
+        RCHK(pointwise(h, content, cn, st + SL.norm[N_DEC0], st + SL.norm[N_DEC0] + 512, false, nullptr, 0, nullptr, nullptr));
+        // normalized_style = (style_map - mean)/std (:397)
+        RCHK(talloc(h, &sn, 1, S.map.H, S.map.W, 512));
+        RCHK(pointwise(h, S.map, sn, st + SL.sty[3], st + SL.sty[3] + 512, true, nullptr, 0, nullptr, nullptr));
+        RCHK(talloc(h, &t32, B, hh, ww, 32));
+        RCHK(talloc(h, &ts32, 1, S.map.H, S.map.W, 32));
+        RCHK(talloc(h, &d32, 1, hh, ww, 32));
+        RCHK(talloc(h, &u, 1, hh, ww, 512));
+        Tens* cur = &cn; Tens* other = &nxt;
+        for (int f = 0; f < 3; ++f) {
+            char pre[64];
+            snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
+            for (int g = 0; g < 2; ++g) {   // FilterPredictor.compute (:161-172) for F1 then F2
+                const ConvW* wp = &h->conv[std::string(pre) + (g ? ".F2" : ".F1") + ".down_sample.0"];
+                ConvCall c{cur, &t32, wp, hh, ww}; c.B = B; RCHK(conv(h, c));
+                RCHK(chan_stats(h, t32, 0, cmean));
+                ConvCall cs{&sn, &ts32, wp, sn.H, sn.W}; RCHK(conv(h, cs));
+                RCHK(chan_stats(h, ts32, 0, smean));
+                hipLaunchKernelGGL(fc_filter_k, dim3(4), dim3(256), 0, h->stream, (const float*)h->fc_w[2 * f + g],
+                                   (const float*)h->fc_b[2 * f + g], (const float*)cmean, (const float*)smean, st + SL.filt[2 * f + g]);
+                HIPCHK(hipGetLastError());
+            }
+            RCHK(fold_filters(h, st, f));
+            // KernelFilter.compute (:223-230): only frame 0 passes through apply_filter (Q1)
+            Tens cur0 = *cur; cur0.B = 1;
+            ConvCall c{&cur0, &d32, &h->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
+            ConvCall cu{&d32, &u, &h->fold_up[f], hh, ww}; RCHK(conv(h, cu));
+            RCHK(pointwise(h, *cur, *other, nullptr, nullptr, false, &u, 1, nullptr, nullptr));
+            Tens* t = cur; cur = other; other = t;
+        }
+        h->active_src = -1;   // folded weights now belong to this style's blob; re-activate below
+        // AdaIN_compute(1) (:428)
+        RCHK(chan_stats(h, *cur, 1, st + SL.norm[N_DEC1]));
+        RCHK(pointwise(h, *cur, *cur, st + SL.norm[N_DEC1], st + SL.norm[N_DEC1] + 512, false, nullptr, 0, st + SL.sty[3], st + SL.sty[3] + 512));
+        struct Blk { const char* name; int cout, n1, n2, nada, sty; };
+        const Blk blks[3] = {{"slice4", 256, N_S4N1, N_S4N2, N_DEC2, 2}, {"slice3", 128, N_S3N1, N_S3N2, N_DEC3, 1}, {"slice2", 64, N_S2N1, N_S2N2, N_DEC4, 0}};
+        Tens in = *cur;   // shallow view
+        Tens prev_o;      // owns previous block output
+        for (int k = 0; k < 3; ++k) {
+            const Blk& b = blks[k];
+            const std::string p = std::string("Decoder.") + b.name;
+            const int H2 = in.H * 2, W2 = in.W * 2;
+            RCHK(talloc(h, &xs, B, in.H, in.W, b.cout));
+            RCHK(talloc(h, &a, B, H2, W2, b.cout));
+            RCHK(talloc(h, &o, B, H2, W2, b.cout));
+            ConvCall c;
+            c = ConvCall{&in, &xs, &h->conv[p + ".conv_shortcut"], in.H, in.W}; c.B = B; RCHK(conv(h, c));
+            c = ConvCall{&in, &a, &h->conv[p + ".conv1"], H2, W2}; c.B = B; c.ups = true; c.epi = E_LRELU; RCHK(conv(h, c));
+            RCHK(chan_stats(h, a, 1, st + SL.norm[b.n1]));
+            RCHK(pointwise(h, a, a, st + SL.norm[b.n1], st + SL.norm[b.n1] + b.cout, false, nullptr, 0, nullptr, nullptr));
+            c = ConvCall{&a, &o, &h->conv[p + ".conv2"], H2, W2}; c.B = B; c.epi = E_LRELU; RCHK(conv(h, c));
+            RCHK(chan_stats(h, o, 1, st + SL.norm[b.n2]));
+            RCHK(pointwise(h, o, o, st + SL.norm[b.n2], st + SL.norm[b.n2] + b.cout, false, &xs, 2, nullptr, nullptr));
+            // AdaIN_compute(k+2)
+            RCHK(chan_stats(h, o, 1, st + SL.norm[b.nada]));
+            if (k < 2)
+                RCHK(pointwise(h, o, o, st + SL.norm[b.nada], st + SL.norm[b.nada] + b.cout, false, nullptr, 0, st + SL.sty[b.sty], st + SL.sty[b.sty] + b.cout));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            tfree(&prev_o);
+            prev_o = o; o.p = nullptr;
+            in = prev_o;
+            tfree(&xs); tfree(&a);
+        }
+        tfree(&prev_o);
+        return RRV_OK;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(h->stream);
+    tfree(&cn); tfree(&nxt); tfree(&sn); tfree(&t32); tfree(&ts32); tfree(&d32); tfree(&u); tfree(&xs); tfree(&a); tfree(&o);
+    (void)hipFree(cmean); (void)hipFree(smean);
+    if (rc == RRV_OK) S.computed = true;
+    return rc;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int rrv_create(int device, rrv_handle* out) {
+    if (!out) return RRV_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return RRV_E_HIP;
+    rrv_ctx* h = new rrv_ctx();
+    h->dev = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return RRV_E_HIP;
+    }
+    *out = h;
+    return RRV_OK;
+}
+
+int rrv_destroy(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    (void)hipSetDevice(h->dev);
+    (void)hipDeviceSynchronize();
+    // device memory is released with the process / context; free the big pieces explicitly
+    for (auto& kv : h->conv) { if (kv.second.raw) (void)hipFree(kv.second.raw); if (kv.second.pk) (void)hipFree(kv.second.pk); }
+    for (float* p : h->patches) (void)hipFree(p);
+    for (EncPlan* e : {&h->enc_frame, &h->enc_add, &h->enc_style})
+        for (Tens* t : {&e->c11, &e->p1, &e->c21, &e->p2, &e->c31, &e->c32, &e->c33, &e->p3, &e->c41}) tfree(t);
+    DecPlan& d = h->dec;
+    for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2}) tfree(t);
+    for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); tfree(&s.map); }
+    if (h->d_u8) (void)hipFree(h->d_u8);
+    if (h->d_outf) (void)hipFree(h->d_outf);
+    for (ProfEntry& e : h->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RRV_OK;
+}
+
+const char* rrv_last_error(rrv_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int rrv_load_weight(rrv_handle h, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!h || !key || !data || !shape || ndim < 1 || ndim > 4) return RRV_E_ARG;
+    if (h->finalized) return fail(h, RRV_E_WEIGHTS, "weights already finalized");
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    h->hostw[key].assign(data, data + n);
+    h->hostshape[key].assign(shape, shape + ndim);
+    return RRV_OK;
+}
+
+int rrv_finalize_weights(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    if (h->finalized) return RRV_OK;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(dalloc(h, &h->zero_bias, 512, true));
+    for (int which = 0; which < 2; ++which) {
+        for (int i = 0; i < 9; ++i) {
+            char k[64];
+            if (which == 0) snprintf(k, sizeof k, "Encoder.slice.%d", VGG_IDX[i]);
+            else snprintf(k, sizeof k, "EncoderStyle.slice%d.%d", STYLE_SLICE[i], VGG_IDX[i]);
+            if (i == 0) {
+                float* raw = nullptr;
+                RCHK(upload(h, std::string(k) + ".weight", &raw, 64 * 27));
+                RCHK(dalloc(h, &h->first_w[which], 27 * 64, false));
+                hipLaunchKernelGGL(pack_first_k, dim3(7), dim3(256), 0, h->stream, (const float*)raw, h->first_w[which]);
+                HIPCHK(hipGetLastError());
+                RCHK(upload(h, std::string(k) + ".bias", &h->first_b[which], 64));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                (void)hipFree(raw);
+            } else {
+                RCHK(make_conv(h, k, VGG_COUT[i], VGG_CIN[i], 9, true));
+            }
+        }
+    }
+    const int bc[3][2] = {{512, 256}, {256, 128}, {128, 64}};
+    const char* bn[3] = {"slice4", "slice3", "slice2"};
+    for (int b = 0; b < 3; ++b) {
+        const std::string p = std::string("Decoder.") + bn[b];
+        RCHK(make_conv(h, p + ".conv1", bc[b][1], bc[b][0], 9, true));
+        RCHK(make_conv(h, p + ".conv2", bc[b][1], bc[b][1], 9, true));
+        RCHK(make_conv(h, p + ".conv_shortcut", bc[b][1], bc[b][0], 1, false));
+    }
+    {
+        float* raw = nullptr;
+        RCHK(upload(h, "Decoder.slice1.weight", &raw, 3 * 64 * 9));
+        RCHK(dalloc(h, &h->last_w, 9 * 64 * 4, false));
+        hipLaunchKernelGGL(pack_last_k, dim3(9), dim3(256), 0, h->stream, (const float*)raw, h->last_w);
+        HIPCHK(hipGetLastError());
+        RCHK(dalloc(h, &h->last_b, 4, true));
+        auto it = h->hostw.find("Decoder.slice1.bias");
+        if (it == h->hostw.end() || it->second.size() != 3) return fail(h, RRV_E_WEIGHTS, "missing weight Decoder.slice1.bias");
+        HIPCHK(hipMemcpyAsync(h->last_b, it->second.data(), 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (void)hipFree(raw);
+    }
+    for (int f = 0; f < 3; ++f) {
+        char pre[64];
+        snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
+        RCHK(make_conv(h, std::string(pre) + ".down_sample.0", 32, 512, 9, true, false));
+        RCHK(make_conv(h, std::string(pre) + ".upsample.0", 512, 32, 9, true, false));
+        for (int g = 0; g < 2; ++g) {
+            const std::string q = std::string(pre) + (g ? ".F2" : ".F1");
+            RCHK(make_conv(h, q + ".down_sample.0", 32, 512, 9, true));
+            RCHK(upload(h, q + ".FC.weight", &h->fc_w[2 * f + g], 1024 * 64));
+            RCHK(upload(h, q + ".FC.bias", &h->fc_b[2 * f + g], 1024));
+        }
+        ConvW& fd = h->fold_down[f];
+        fd.Cout = 32; fd.Cin = 512; fd.taps = 9; fd.BN = 32;
+        RCHK(dalloc(h, &fd.raw, 32 * 512 * 9)); RCHK(dalloc(h, &fd.pk, 32 * 512 * 9)); RCHK(dalloc(h, &fd.bias, 32));
+        ConvW& fu = h->fold_up[f];
+        fu.Cout = 512; fu.Cin = 32; fu.taps = 9; fu.BN = 128;
+        RCHK(dalloc(h, &fu.raw, 512 * 32 * 9)); RCHK(dalloc(h, &fu.pk, 512 * 32 * 9));
+        fu.bias = h->conv[std::string(pre) + ".upsample.0"].bias;
+    }
+    RCHK(dalloc(h, &h->active, RRV_STATE_FLOATS));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->hostw.clear();
+    h->finalized = true;
+    return RRV_OK;
+}
+
+int rrv_prepare_style(rrv_handle h, const uint8_t* style, int Hs, int Ws, int sid) {
+    if (!h || !style || Hs < 8 || Ws < 8 || sid < 0 || sid >= RRV_MAX_STYLES) return RRV_E_ARG;
+    if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
+    HIPCHK(hipSetDevice(h->dev));
+    StyleState& S = h->styles[sid];
+    if (!S.blob) RCHK(dalloc(h, &S.blob, RRV_STATE_FLOATS));
+    RCHK(ensure_u8(h, (size_t)Hs * Ws * 3));
+    HIPCHK(hipMemcpyAsync(h->d_u8, style, (size_t)Hs * Ws * 3, hipMemcpyHostToDevice, h->stream));
+    RCHK(enc_plan(h, h->enc_style, Hs, Ws));
+    EncPlan& e = h->enc_style;
+    RCHK(run_encoder(h, e, h->d_u8, 1, nullptr));
+    // cal_mean_std at relu1_1..relu4_1 (style_network_global.py:304-331)
+    const Tens* taps[4] = {&e.c11, &e.c21, &e.c31, &e.c41};
+    for (int k = 0; k < 4; ++k) RCHK(chan_stats(h, *taps[k], 2, S.blob + SL.sty[k]));
+    RCHK(talloc(h, &S.map, 1, e.c41.H, e.c41.W, 512));
+    HIPCHK(hipMemcpyAsync(S.map.p, e.c41.p, e.c41.img_floats() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    S.prepared = true; S.computed = false;
+    if (h->active_src == sid) h->active_src = -1;
+    return RRV_OK;
+}
+
+int rrv_clean(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    (void)hipSetDevice(h->dev);
+    (void)hipStreamSynchronize(h->stream);
+    for (float* p : h->patches) (void)hipFree(p);
+    h->patches.clear();
+    h->patch_h = h->patch_w = h->add_H = h->add_W = 0;
+    for (StyleState& s : h->styles) s.computed = false;
+    h->active_src = -1;
+    return RRV_OK;
+}
+
+int rrv_add(rrv_handle h, const uint8_t* frame, int H, int W) {
+    if (!h || !frame || H < 8 || W < 8) return RRV_E_ARG;
+    if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
+    HIPCHK(hipSetDevice(h->dev));
+    if (!h->patches.empty() && (H != h->add_H || W != h->add_W))
+        return fail(h, RRV_E_ARG, "add: all sampled frames must have the same size");
+    RCHK(ensure_u8(h, (size_t)H * W * 3));
+    HIPCHK(hipMemcpyAsync(h->d_u8, frame, (size_t)H * W * 3, hipMemcpyHostToDevice, h->stream));
+    RCHK(enc_plan(h, h->enc_add, H, W));
+    RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr));
+    const Tens& f = h->enc_add.c41;
+    float* keep = nullptr;
+    RCHK(dalloc(h, &keep, f.img_floats(), false));
+    HIPCHK(hipMemcpyAsync(keep, f.p, f.img_floats() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->patches.push_back(keep);
+    h->patch_h = f.H; h->patch_w = f.W; h->add_H = H; h->add_W = W;
+    return RRV_OK;
+}
+
+int rrv_compute(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    if (h->patches.empty()) return fail(h, RRV_E_STATE, "compute: no frames added");
+    int nprep = 0;
+    for (StyleState& s : h->styles) nprep += s.prepared ? 1 : 0;
+    if (!nprep) return fail(h, RRV_E_STATE, "compute: prepare_style has not been called");
+    Tens content;
+    const int B = (int)h->patches.size();
+    RCHK(talloc(h, &content, B, h->patch_h, h->patch_w, 512));
+    for (int b = 0; b < B; ++b)
+        HIPCHK(hipMemcpyAsync(content.p + (size_t)b * content.img_floats(), h->patches[b], content.img_floats() * sizeof(float),
+                              hipMemcpyDeviceToDevice, h->stream));
+    int rc = RRV_OK, first = -1;
+    for (int s = 0; s < RRV_MAX_STYLES && rc == RRV_OK; ++s)
+        if (h->styles[s].prepared) { rc = compute_style(h, s, content); if (first < 0) first = s; }
+    (void)hipStreamSynchronize(h->stream);
+    tfree(&content);
+    if (rc != RRV_OK) return rc;
+    h->active_src = -1;
+    return activate_state(h, first);
+}
+
+int rrv_get_state(rrv_handle h, float* out, int n, int sid) {
+    if (!h || !out || n != RRV_STATE_FLOATS || sid < 0 || sid >= RRV_MAX_STYLES) return RRV_E_ARG;
+    StyleState& S = h->styles[sid];
+    if (!S.blob || !S.computed) return fail(h, RRV_E_STATE, "get_state: state not computed for this style");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, S.blob, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return RRV_OK;
+}
+
+int rrv_set_state(rrv_handle h, const float* in, int n, int sid) {
+    if (!h || !in || n != RRV_STATE_FLOATS || sid < 0 || sid >= RRV_MAX_STYLES) return RRV_E_ARG;
+    if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
+    HIPCHK(hipSetDevice(h->dev));
+    StyleState& S = h->styles[sid];
+    if (!S.blob) RCHK(dalloc(h, &S.blob, RRV_STATE_FLOATS));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(S.blob, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    S.computed = true;
+    if (h->active_src == sid || h->active_src == -1) { h->active_src = -1; RCHK(activate_state(h, sid)); }
+    return RRV_OK;
+}
+
+int rrv_transfer_device(rrv_handle h, const void* d_in, int H, int W, void* d_out) {
+    if (!h || !d_in || !d_out) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    if (h->active_src == -2) h->active_src = -1;
+    if (h->active_src == -1) {
+        for (int s = 0; s < RRV_MAX_STYLES; ++s)
+            if (h->styles[s].computed) { RCHK(activate_state(h, s)); break; }
+    }
+    return transfer_device(h, (const uint8_t*)d_in, H, W, (float*)d_out);
+}
+
+int rrv_transfer_blend_device(rrv_handle h, const void* d_in, int H, int W, const float* wts, int ns, void* d_out) {
+    if (!h || !d_in || !d_out || !wts || ns < 1 || ns > RRV_MAX_STYLES) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    BlendP bp{};
+    bp.n = ns; bp.out = h->active; bp.count = RRV_STATE_FLOATS;
+    for (int s = 0; s < ns; ++s) {
+        if (!h->styles[s].computed) return fail(h, RRV_E_STATE, "blend: state not computed for every style");
+        bp.st[s] = h->styles[s].blob; bp.w[s] = wts[s];
+    }
+    hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
+    HIPCHK(hipGetLastError());
+    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
+    h->active_src = -2;
+    return transfer_device(h, (const uint8_t*)d_in, H, W, (float*)d_out);
+}
+
+int rrv_transfer(rrv_handle h, const uint8_t* frame, int H, int W, float* out) {
+    if (!h || !frame || !out) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t n = (size_t)H * W * 3;
+    RCHK(ensure_u8(h, n));
+    if (h->d_outf_cap < n) {
+        if (h->d_outf) (void)hipFree(h->d_outf);
+        HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
+        h->d_outf_cap = n;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_u8, frame, n, hipMemcpyHostToDevice, h->stream));
+    RCHK(rrv_transfer_device(h, h->d_u8, H, W, h->d_outf));
+    HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RRV_OK;
+}
+
+int rrv_get_preclamp(rrv_handle h, float* out, int H, int W) {
+    if (!h || !out) return RRV_E_ARG;
+    if (!h->dec.pre || h->dec.H != H || h->dec.W != W) return fail(h, RRV_E_STATE, "get_preclamp: no transfer of that size yet");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->dec.pre, (size_t)H * W * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return RRV_OK;
+}
+
+int rrv_sync(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RRV_OK;
+}
+
+int rrv_profile_begin(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    for (ProfEntry& e : h->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    h->prof.clear();
+    h->profiling = true;
+    return RRV_OK;
+}
+
+int rrv_profile_end(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    h->profiling = false;
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (ProfEntry& e : h->prof) HIPCHK(hipEventElapsedTime(&e.ms, e.e0, e.e1));
+    return RRV_OK;
+}
+
+int rrv_profile_count(rrv_handle h) { return h ? (int)h->prof.size() : RRV_E_ARG; }
+
+int rrv_profile_entry(rrv_handle h, int i, const char** name, float* ms, double* flops, double* bytes) {
+    if (!h || i < 0 || i >= (int)h->prof.size()) return RRV_E_ARG;
+    const ProfEntry& e = h->prof[i];
+    if (name) *name = e.name;
+    if (ms) *ms = e.ms;
+    if (flops) *flops = e.flops;
+    if (bytes) *bytes = e.bytes;
+    return RRV_OK;
+}
+
+}  // extern "C"

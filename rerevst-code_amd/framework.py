@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference drop-in boundary ``Stylization``
+(test/framework.py:56-118): same method names, argument meaning and return types, so a
+``generate_real_video.py``-style driver runs unchanged.  All compute happens in
+librerevst_hip.so on one MI355X; this class only marshals numpy buffers through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .weights import weight_table, load_checkpoint
+
+
+class RRVError(RuntimeError):
+    pass
+
+
+def _u8_image(img, what):
+    a = np.ascontiguousarray(img)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("%s must be uint8 HWC BGR with 3 channels, got %s %s" % (what, a.dtype, a.shape))
+    return a
+
+
+class Stylization():
+    """``Stylization(checkpoint, cuda=True, use_Global=True)`` (test/framework.py:57).
+
+    `checkpoint` is a path to the reference ``.pth`` state_dict, or a ``{key: ndarray}``
+    dict with the same keys (used with the seeded synthetic weights, since the released
+    checkpoint is download-only).  `device` picks the HIP device ordinal (one process per
+    GPU; defaults to LOCAL_RANK or 0).
+    """
+
+    def __init__(self, checkpoint, cuda=True, use_Global=True, device=None, style_num=1):
+        if not cuda:
+            raise RRVError("this implementation only runs on an MI355X GPU (cuda=False has no CPU fallback)")
+        if not use_Global:
+            raise NotImplementedError("use_Global=False (style_network_frame.py) is not built yet (SURVEY.md §8(f) rank 3)")
+        self._lib = _lib.load()
+        if device is None:
+            import os
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = int(device)
+        self.style_num = int(style_num)
+        self._h = C.c_void_p()
+        rc = self._lib.rrv_create(self.device, C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise RRVError("rrv_create(device=%d) failed with %d (no HIP device?)" % (self.device, rc))
+        weights = checkpoint if isinstance(checkpoint, dict) else load_checkpoint(checkpoint)
+        for key, shape in weight_table().items():     # strict: every key, exact shape
+            if key not in weights:
+                raise KeyError("missing weight %s" % key)
+            w = np.ascontiguousarray(weights[key], dtype=np.float32)
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError("weight %s has shape %s, expected %s" % (key, w.shape, shape))
+            shp = (C.c_int64 * w.ndim)(*w.shape)
+            self._chk(self._lib.rrv_load_weight(self._h, key.encode(), w.ctypes.data_as(C.c_void_p), shp, w.ndim))
+        self._chk(self._lib.rrv_finalize_weights(self._h))
+
+    # ------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._lib.rrv_last_error(self._h)
+            raise RRVError("librerevst_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rrv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ===== Sequence-Level Global Feature Sharing (test/framework.py:82-95) =====
+    def add(self, patch):
+        a = _u8_image(patch, "patch")
+        self._chk(self._lib.rrv_add(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]))
+
+    def compute(self):
+        self._chk(self._lib.rrv_compute(self._h))
+
+    def clean(self):
+        self._chk(self._lib.rrv_clean(self._h))
+
+    # ===== Style Transfer (test/framework.py:99-118) =====
+    def prepare_style(self, style):
+        """Single style image (test/framework.py:99) or a list of them
+        ("Multi-style Interpolation/stylization.py":71)."""
+        styles = style if isinstance(style, (list, tuple)) else [style]
+        for sid, s in enumerate(styles):
+            a = _u8_image(s, "style")
+            self._chk(self._lib.rrv_prepare_style(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], sid))
+
+    def transfer(self, frame, style_weight=None):
+        """uint8 BGR HWC frame -> float32 BGR HWC in 0..255 (test/framework.py:106-118).
+        With `style_weight` (list of floats) the saved state of the prepared styles is
+        blended first (stylization.py:94-100)."""
+        a = _u8_image(frame, "frame")
+        H, W = a.shape[:2]
+        out = np.empty((H, W, 3), dtype=np.float32)
+        if style_weight is None:
+            self._chk(self._lib.rrv_transfer(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p)))
+            return out
+        import torch  # plumbing: device buffers for the blend entry point
+        dev = torch.device("cuda", self.device)
+        d_in = torch.from_numpy(a).to(dev)
+        d_out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        w = (C.c_float * len(style_weight))(*[float(v) for v in style_weight])
+        self._chk(self._lib.rrv_transfer_blend_device(self._h, d_in.data_ptr(), H, W, w, len(style_weight), d_out.data_ptr()))
+        self.sync()
+        return d_out.cpu().numpy()
+
+    # ===== device-resident entry (what bench.py times) =====
+    def transfer_device(self, d_in_ptr, H, W, d_out_ptr):
+        self._chk(self._lib.rrv_transfer_device(self._h, C.c_void_p(d_in_ptr), H, W, C.c_void_p(d_out_ptr)))
+
+    def sync(self):
+        self._chk(self._lib.rrv_sync(self._h))
+
+    # ===== shared state (RCCL broadcast payload / golden comparison) =====
+    def get_state(self, style_id=0):
+        out = np.empty(_lib.STATE_FLOATS, dtype=np.float32)
+        self._chk(self._lib.rrv_get_state(self._h, out.ctypes.data_as(C.c_void_p), out.size, style_id))
+        return out
+
+    def set_state(self, blob, style_id=0):
+        b = np.ascontiguousarray(blob, dtype=np.float32).reshape(-1)
+        if b.size != _lib.STATE_FLOATS:
+            raise ValueError("state blob must have %d floats" % _lib.STATE_FLOATS)
+        self._chk(self._lib.rrv_set_state(self._h, b.ctypes.data_as(C.c_void_p), b.size, style_id))
+
+    def preclamp(self, H, W):
+        """Pre-clamp network output of the last transfer, NHWC RGB normalised units."""
+        out = np.empty((H, W, 3), dtype=np.float32)
+        self._chk(self._lib.rrv_get_preclamp(self._h, out.ctypes.data_as(C.c_void_p), H, W))
+        return out
+
+    # ===== per-launch timing (HIP events on the library's stream) =====
+    def profile_begin(self):
+        self._chk(self._lib.rrv_profile_begin(self._h))
+
+    def profile_end(self):
+        self._chk(self._lib.rrv_profile_end(self._h))
+        n = self._lib.rrv_profile_count(self._h)
+        rows = []
+        name, ms, fl, by = C.c_char_p(), C.c_float(), C.c_double(), C.c_double()
+        for i in range(n):
+            self._chk(self._lib.rrv_profile_entry(self._h, i, C.byref(name), C.byref(ms), C.byref(fl), C.byref(by)))
+            rows.append((name.value.decode(), ms.value, fl.value, by.value))
+        return rows

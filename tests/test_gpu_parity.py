@@ -1,0 +1,58 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(ctypes Stylization), against the committed reference goldens and against the CPU oracle on
+the same seeded inputs."""
+import numpy as np
+import pytest
+
+from conftest import (load_golden, golden_inputs, assert_state_close, assert_pre_close, IMG_ATOL)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(pkg, weights):
+    s = pkg.Stylization(weights, cuda=True)
+    yield s
+    s.close()
+
+
+def test_transfer_with_golden_state(hip, pkg, oracle):
+    """Per-frame path alone: state injected from the reference golden (set_state)."""
+    g = load_golden("global_a")
+    _, frames, _, tid = golden_inputs(pkg, g)
+    hip.set_state(g["state"])
+    padded = oracle.reflect_pad(frames[tid], 192, 192)
+    out = hip.transfer(padded)
+    assert out.dtype == np.float32 and out.shape == (192, 192, 3)
+    assert_pre_close(hip.preclamp(192, 192), g["pre"])
+    assert np.abs(out - g["out"]).max() <= IMG_ATOL
+
+
+@pytest.mark.parametrize("case", ["global_a", "global_b"])
+def test_full_pipeline_matches_reference(case, hip, pkg, oracle):
+    """prepare_style -> clean -> add* -> compute -> transfer, all on the GPU."""
+    g = load_golden(case)
+    style, frames, ids, tid = golden_inputs(pkg, g)
+    hip.prepare_style(style)
+    hip.clean()
+    for i in ids:
+        hip.add(frames[i])
+    hip.compute()
+    assert_state_close(hip.get_state(), g["state"])
+    H, W = frames[0].shape[:2]
+    PH, PW = oracle.padded_size(H), oracle.padded_size(W)
+    out = hip.transfer(oracle.reflect_pad(frames[tid], PH, PW))
+    pre = hip.preclamp(PH, PW)
+    if "pre" in g.files:
+        assert_pre_close(pre, g["pre"])
+        assert np.abs(out - g["out"]).max() <= IMG_ATOL
+    else:
+        assert_pre_close(pre[64:64 + H, 64:64 + W], g["pre_crop"])
+        assert np.abs(out[64:64 + H, 64:64 + W] - g["out_crop"]).max() <= IMG_ATOL
+
+
+def test_transfer_before_compute_is_an_error(pkg, weights):
+    s = pkg.Stylization(weights, cuda=True)
+    with pytest.raises(pkg.RRVError, match="state not computed"):
+        s.transfer(np.zeros((64, 64, 3), np.uint8))
+    s.close()
