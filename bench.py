@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""Throughput bench of the per-frame stylization path (BASELINE.json metric:
+stylized frames/sec at 512x512, 1 style).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one `transfer` of one 512x512 synthetic frame (reflect-padded to 640x640 as
+generate_real_video.py:61-83 does) per GPU, uint8 frame resident in HBM -> float32 BGR frame
+in HBM.  N>1: one process per GPU (torch.distributed / RCCL), rank 0 runs prepare_style +
+add + compute and broadcasts the 70 KB shared state; frames are sharded, no per-frame
+communication ("weak" scaling: every rank stylizes K frames).  Prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=512, help="frame side (256/512/1024)")
+    ap.add_argument("--frames", type=int, default=300, help="frames of the synthetic video")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    pkg = importlib.import_module("rerevst-code_amd")
+    video = importlib.import_module("rerevst-code_amd.video")
+    S, NF = args.size, args.frames
+    P = video.padded_size(S)
+
+    weights = pkg.synthetic_weights(0)
+    model = pkg.Stylization(weights, cuda=True, device=local)
+
+    # ---- synthetic video: this rank's shard, padded, resident in HBM --------------------
+    n_local = min(NF, max(args.steps, 1))
+    first = (rank * args.steps) % NF
+    my_ids = [(first + i) % NF for i in range(n_local)]
+    host = np.stack([video.reflect_pad(pkg.synth_frame(i, S, S, kind="noise"), P, P) for i in my_ids])
+    d_frames = torch.from_numpy(host).to(dev)
+    d_out = torch.empty((4, P, P, 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    # ---- once-per-video preparation on rank 0, state broadcast over RCCL ------------------
+    t0 = time.time()
+    blob = torch.empty(17536, dtype=torch.float32, device=dev)
+    if rank == 0:
+        model.prepare_style(pkg.synth_style(512, 512, kind="noise", seed=7))
+        model.clean()
+        for i in video.sample_indices(NF):
+            model.add(pkg.synth_frame(i, S, S, kind="noise"))      # unpadded (generate_real_video.py:139-143)
+        model.compute()
+        blob.copy_(torch.from_numpy(model.get_state()))
+    prep_s = time.time() - t0
+    if world > 1:
+        dist.broadcast(blob, src=0)
+        if rank != 0:
+            model.set_state(blob.cpu().numpy())
+
+    def step(i):
+        k = i % n_local
+        model.transfer_device(d_frames[k].data_ptr(), P, P, d_out[i & 3].data_ptr())
+
+    for i in range(args.warmup):
+        step(i)
+    model.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    nprof = max(0, min(args.profile_steps, args.steps))
+    t0 = time.perf_counter()
+    for i in range(args.steps - nprof):
+        step(i)
+    if nprof:
+        model.profile_begin()          # HIP events on the library's own stream, inside the timed region
+        for i in range(args.steps - nprof, args.steps):
+            step(i)
+        rows = model.profile_end()
+    else:
+        rows = []
+    model.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel from the live per-launch events ---------------
+        agg = {}
+        for name, ms, fl, by in rows:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+        roof, kern = None, []
+        if agg:
+            tot_ms = sum(a[1] for a in agg.values())
+            for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                kern.append({"kernel": name, "launches_per_frame": a[0] / nprof, "ms_per_frame": round(a[1] / nprof, 4),
+                             "tflops": round(a[2] / a[1] / 1e9, 2) if a[1] > 0 else None,
+                             "gbs": round(a[3] / a[1] / 1e6, 1) if a[1] > 0 else None})
+            dom = max(agg.items(), key=lambda kv: kv[1][1])
+            achieved = dom[1][2] / dom[1][1] / 1e9
+            roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom[1][1] / dom[1][0], 5), "share_of_gpu_time": round(dom[1][1] / tot_ms, 3),
+                    "all_mfma_conv_tflops": round(sum(a[2] for n, a in agg.items() if n.startswith("conv_mfma")) /
+                                                  sum(a[1] for n, a in agg.items() if n.startswith("conv_mfma")) / 1e9, 2)}
+        # ---- CPU baseline: the numpy oracle (port) on a bounded sample ----------------------
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import rerevst_oracle as O
+            o = O.Stylization(weights)
+            o.set_state(model.get_state())
+            nsamp = {256: 6, 512: 3, 1024: 1}.get(S, 2)
+            o.transfer(host[0])                       # warm-up
+            tc = time.perf_counter()
+            for k in range(nsamp):
+                o.transfer(host[(k + 1) % n_local])
+            tc = time.perf_counter() - tc
+            try:
+                from threadpoolctl import threadpool_info
+                thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+            except Exception:
+                thr = os.cpu_count()
+            cpu = {"value": round(nsamp / tc, 4), "unit": "frames/s", "cores": int(thr), "kind": "port",
+                   "sample": "%d padded %dx%d frames through oracle/rerevst_oracle.py (numpy fp32, BLAS threads=%d of %d host cores)"
+                             % (nsamp, P, P, thr, os.cpu_count())}
+        out = {"metric": "stylized frames/sec at %dx%d, 1 style" % (S, S), "value": round(world * args.steps / dt, 3),
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%d-frame synthetic %dx%d video (padded %dx%d), 1 style, frames sharded per GPU"
+                                      % (NF, S, S, P, P), "frames_per_step_per_gpu": 1, "sampled_frames": len(video.sample_indices(NF)),
+                          "parallelism": "frame-shard x%d" % world},
+               "roofline": roof, "cpu_baseline": cpu, "prep_seconds_rank0": round(prep_s, 3), "kernels": kern[:8]}
+        print(json.dumps(out), flush=True)
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
