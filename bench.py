@@ -4,9 +4,9 @@ stylized frames/sec at 512x512, 1 style).
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one `transfer` of one 512x512 synthetic frame (reflect-padded to 640x640 as
-generate_real_video.py:61-83 does) per GPU, uint8 frame resident in HBM -> float32 BGR frame
-in HBM.  N>1: one process per GPU (torch.distributed / RCCL), rank 0 runs prepare_style +
+A step = one pass of the per-frame path over one batch of `--batch` 512x512 synthetic frames
+(reflect-padded to 640x640 as generate_real_video.py:61-83 does) per GPU, uint8 frames resident
+in HBM -> float32 BGR frames in HBM.  N>1: one process per GPU (torch.distributed / RCCL), rank 0 runs prepare_style +
 add + compute and broadcasts the 70 KB shared state; frames are sharded, no per-frame
 communication ("weak" scaling: every rank stylizes K frames).  Prints ONE JSON line.
 """
@@ -29,12 +29,13 @@ PEAK_HBM_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
     ap.add_argument("--size", type=int, default=512, help="frame side (256/512/1024)")
     ap.add_argument("--frames", type=int, default=300, help="frames of the synthetic video")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
 
     import torch
@@ -60,12 +61,13 @@ def main():
     model = pkg.Stylization(weights, cuda=True, device=local)
 
     # ---- synthetic video: this rank's shard, padded, resident in HBM --------------------
-    n_local = min(NF, max(args.steps, 1))
-    first = (rank * args.steps) % NF
-    my_ids = [(first + i) % NF for i in range(n_local)]
+    B = args.batch
+    n_batches = max(1, min(NF // B, args.steps))          # distinct batches kept resident
+    first = (rank * args.steps * B) % NF
+    my_ids = [(first + i) % NF for i in range(n_batches * B)]
     host = np.stack([video.reflect_pad(pkg.synth_frame(i, S, S, kind="noise"), P, P) for i in my_ids])
-    d_frames = torch.from_numpy(host).to(dev)
-    d_out = torch.empty((4, P, P, 3), dtype=torch.float32, device=dev)
+    d_frames = torch.from_numpy(host).to(dev).view(n_batches, B, P, P, 3)
+    d_out = torch.empty((2, B, P, P, 3), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     # ---- once-per-video preparation on rank 0, state broadcast over RCCL ------------------
@@ -85,8 +87,7 @@ def main():
             model.set_state(blob.cpu().numpy())
 
     def step(i):
-        k = i % n_local
-        model.transfer_device(d_frames[k].data_ptr(), P, P, d_out[i & 3].data_ptr())
+        model.transfer_batch_device(d_frames[i % n_batches].data_ptr(), B, P, P, d_out[i & 1].data_ptr())
 
     for i in range(args.warmup):
         step(i)
@@ -125,7 +126,7 @@ def main():
         if agg:
             tot_ms = sum(a[1] for a in agg.values())
             for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                kern.append({"kernel": name, "launches_per_frame": a[0] / nprof, "ms_per_frame": round(a[1] / nprof, 4),
+                kern.append({"kernel": name, "launches_per_step": a[0] / nprof, "ms_per_frame": round(a[1] / nprof / B, 4),
                              "tflops": round(a[2] / a[1] / 1e9, 2) if a[1] > 0 else None,
                              "gbs": round(a[3] / a[1] / 1e6, 1) if a[1] > 0 else None})
             dom = max(agg.items(), key=lambda kv: kv[1][1])
@@ -146,7 +147,7 @@ def main():
             o.transfer(host[0])                       # warm-up
             tc = time.perf_counter()
             for k in range(nsamp):
-                o.transfer(host[(k + 1) % n_local])
+                o.transfer(host[(k + 1) % len(host)])
             tc = time.perf_counter() - tc
             try:
                 from threadpoolctl import threadpool_info
@@ -156,14 +157,14 @@ def main():
             cpu = {"value": round(nsamp / tc, 4), "unit": "frames/s", "cores": int(thr), "kind": "port",
                    "sample": "%d padded %dx%d frames through oracle/rerevst_oracle.py (numpy fp32, BLAS threads=%d of %d host cores)"
                              % (nsamp, P, P, thr, os.cpu_count())}
-        out = {"metric": "stylized frames/sec at %dx%d, 1 style" % (S, S), "value": round(world * args.steps / dt, 3),
+        out = {"metric": "stylized frames/sec at %dx%d, 1 style" % (S, S), "value": round(world * args.steps * B / dt, 3),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%d-frame synthetic %dx%d video (padded %dx%d), 1 style, frames sharded per GPU"
-                                      % (NF, S, S, P, P), "frames_per_step_per_gpu": 1, "sampled_frames": len(video.sample_indices(NF)),
+                                      % (NF, S, S, P, P), "frames_per_step_per_gpu": B, "sampled_frames": len(video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
-               "roofline": roof, "cpu_baseline": cpu, "prep_seconds_rank0": round(prep_s, 3), "kernels": kern[:8]}
+               "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu, "prep_seconds_rank0": round(prep_s, 3), "kernels": kern[:8]}
         print(json.dumps(out), flush=True)
     model.close()
     if world > 1:

@@ -82,10 +82,21 @@ int rrv_transfer(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* ou
  * handle's stream; rrv_sync() waits.  This is the entry the throughput bench times. */
 int rrv_transfer_device(rrv_handle h, const void* d_frame_bgr_u8, int H, int W, void* d_out_bgr_f32);
 
+/* B frames per launch ([B][H][W][3] in, [B][H][W][3] out, both in HBM): frames are independent
+ * once the state exists (test/style_network_global.py:499-501), so batching only widens every
+ * kernel's grid -- it removes the workgroup-quantisation loss of the small layers.
+ * rrv_transfer_device(h, in, H, W, out) == rrv_transfer_batch_device(h, in, 1, H, W, out). */
+int rrv_transfer_batch_device(rrv_handle h, const void* d_frames_bgr_u8, int B, int H, int W, void* d_out_bgr_f32);
+
 /* Multi-style transfer (stylization.py:94-100 + style_network.py:432-460): every saved
  * quantity is replaced by sum_s weight[s]*q_s before the same forward.  Device buffers. */
 int rrv_transfer_blend_device(rrv_handle h, const void* d_frame_bgr_u8, int H, int W,
                               const float* style_weight, int n_styles, void* d_out_bgr_f32);
+
+/* Host-buffer forms of the two entries above (H2D copy, same device path, D2H copy). */
+int rrv_transfer_batch(rrv_handle h, const uint8_t* frames_bgr, int B, int H, int W, float* out_bgr);
+int rrv_transfer_blend(rrv_handle h, const uint8_t* frame_bgr, int H, int W, const float* style_weight, int n_styles,
+                       float* out_bgr);
 
 /* Debug/parity taps: pre-clamp network output (normalised RGB, NHWC [H][W][3]) of the last
  * transfer, copied to host. */

@@ -29,7 +29,10 @@ SYMBOLS = {
     "rrv_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_transfer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rrv_transfer_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rrv_transfer_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rrv_transfer_blend_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "rrv_transfer_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rrv_transfer_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "rrv_get_preclamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_sync": (C.c_int, [C.c_void_p]),
     "rrv_profile_begin": (C.c_int, [C.c_void_p]),
@@ -40,6 +43,25 @@ SYMBOLS = {
 }
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (SONAME libamdhip64.so.7, NEEDED by torch as "libamdhip64.so"); if our library pulled
+    /opt/rocm's copy in first, a later `import torch` would load a SECOND runtime that sees
+    no GPU.  Pre-loading torch's copy (when torch is installed) makes both bind to it,
+    whatever the import order.  RRV_SYSTEM_HIP=1 skips this."""
+    if os.environ.get("RRV_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load the HIP library (once).  Raises OSError with a build hint when it is absent."""
     global _lib
@@ -48,6 +70,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError("%s not found: build it with `python __graft_entry__.py build` "
                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol

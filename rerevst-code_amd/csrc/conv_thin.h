@@ -93,12 +93,12 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
 }
 
 struct LastP {
-    const float* in;      // [1,H,W,64] ring layout
-    int H, W;
+    const float* in;      // [B,H,W,64] ring layout
+    int H, W, B;
     const float* w;       // [9][64][4]: tap, cin, cout(rgb, padded to 4)
     const float* bias;    // [4]
-    float* out_img;       // [H][W][3] BGR float32 0..255
-    float* out_pre;       // optional [H][W][3] RGB pre-clamp (normalised units), may be null
+    float* out_img;       // [B][H][W][3] BGR float32 0..255
+    float* out_pre;       // optional [B][H][W][3] RGB pre-clamp (normalised units), may be null
     int tiles_x, tiles_y;
 };
 
@@ -106,15 +106,19 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
     // 18x18 halo x 16 channels per stage, XOR-swizzled 16-byte pieces
     __shared__ __attribute__((aligned(16))) float s_in[2][18 * 18 * 16];
     const int tid = threadIdx.x;
-    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y, b = bx / p.tiles_y;
     const int y0 = ty * 16, x0 = tx * 16;
     const int py = tid >> 4, px = tid & 15;
+    const float* in_b = p.in + (size_t)b * (size_t)(p.H + 2) * (p.W + 2) * 64;
 
     auto stage = [&](int chunk, int buf) {
         for (int e = tid; e < 18 * 18 * 4; e += 256) {
             const int pp = e >> 2, qq = e & 3;
             const int hy = pp / 18, hx = pp - hy * 18;
-            const float* src = p.in + ((size_t)(y0 + hy) * (p.W + 2) + x0 + hx) * 64 + chunk * 16 + 4 * (qq ^ ((pp >> 2) & 3));
+            const float* src = in_b + ((size_t)(y0 + hy) * (p.W + 2) + x0 + hx) * 64 + chunk * 16 + 4 * (qq ^ ((pp >> 2) & 3));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)((char*)&s_in[buf][0] + (e - (tid & 63)) * 16),
                                              16, 0, 0);
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
     const int y = y0 + py, x = x0 + px;
     if (y < p.H && x < p.W) {
         const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
-        const size_t o = ((size_t)y * p.W + x) * 3;
+        const size_t o = (((size_t)b * p.H + y) * p.W + x) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float t = acc[c] + p.bias[c];

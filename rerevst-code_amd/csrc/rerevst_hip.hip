@@ -53,12 +53,12 @@ const int VGG_CIN[9] = {3, 64, 64, 128, 128, 256, 256, 256, 256};
 const int VGG_COUT[9] = {64, 64, 128, 128, 256, 256, 256, 256, 512};
 const int STYLE_SLICE[9] = {1, 2, 2, 3, 3, 4, 4, 4, 4};
 
-struct EncPlan {   // encoder activations for one (B=1, H, W)
-    int H = 0, W = 0;
+struct EncPlan {   // encoder activations for one (B, H, W)
+    int B = 0, H = 0, W = 0;
     Tens c11, p1, c21, p2, c31, c32, c33, p3, c41;
 };
-struct DecPlan {   // per-frame decoder activations for one (H, W) of the FRAME
-    int H = 0, W = 0;
+struct DecPlan {   // per-frame decoder activations for one (B, H, W) of the FRAME batch
+    int B = 0, H = 0, W = 0;
     Tens d, f1, f2, f3, xs4, a4, o4, xs3, a3, o3, xs2, a2, o2;
     float* pre = nullptr;   // [H][W][3] pre-clamp tap
 };
@@ -314,29 +314,29 @@ int activate_state(rrv_handle h, int style_id) {
 }
 
 // ---- encoder ----------------------------------------------------------------------------
-int enc_plan(rrv_handle h, EncPlan& e, int H, int W) {
-    if (e.H == H && e.W == W && e.c11.p) return RRV_OK;
-    e.H = H; e.W = W;
+int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {
+    if (e.B == B && e.H == H && e.W == W && e.c11.p) return RRV_OK;
+    e.B = B; e.H = H; e.W = W;
     const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
-    RCHK(talloc(h, &e.c11, 1, H, W, 64));
-    RCHK(talloc(h, &e.p1, 1, H2, W2, 64));
-    RCHK(talloc(h, &e.c21, 1, H2, W2, 128));
-    RCHK(talloc(h, &e.p2, 1, H4, W4, 128));
-    RCHK(talloc(h, &e.c31, 1, H4, W4, 256));
-    RCHK(talloc(h, &e.c32, 1, H4, W4, 256));
-    RCHK(talloc(h, &e.c33, 1, H4, W4, 256));
-    RCHK(talloc(h, &e.p3, 1, H8, W8, 256));
-    RCHK(talloc(h, &e.c41, 1, H8, W8, 512));
+    RCHK(talloc(h, &e.c11, B, H, W, 64));
+    RCHK(talloc(h, &e.p1, B, H2, W2, 64));
+    RCHK(talloc(h, &e.c21, B, H2, W2, 128));
+    RCHK(talloc(h, &e.p2, B, H4, W4, 128));
+    RCHK(talloc(h, &e.c31, B, H4, W4, 256));
+    RCHK(talloc(h, &e.c32, B, H4, W4, 256));
+    RCHK(talloc(h, &e.c33, B, H4, W4, 256));
+    RCHK(talloc(h, &e.p3, B, H8, W8, 256));
+    RCHK(talloc(h, &e.c41, B, H8, W8, 512));
     return RRV_OK;
 }
 
 // vgg19.features[0:21] on a device-resident uint8 BGR image.  which: 0 Encoder (grey), 1 EncoderStyle (colour).
 // norm0 != nullptr fuses Decoder.norm[0] into the last conv (per-frame path).
 int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0) {
-    const int H = e.H, W = e.W;
-    FirstP fp{d_img, H, W, 1, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16};
-    RCHK(launch(h, "conv_first", 2.0 * H * W * 27 * 64, 3.0 * H * W + 256.0 * H * W, [&] {
-        hipLaunchKernelGGL(conv_first_k, dim3(fp.tiles_x * fp.tiles_y), dim3(256), 0, h->stream, fp);
+    const int H = e.H, W = e.W, B = e.B;
+    FirstP fp{d_img, H, W, B, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16};
+    RCHK(launch(h, "conv_first", 2.0 * B * H * W * 27 * 64, (3.0 + 256.0) * B * H * W, [&] {
+        hipLaunchKernelGGL(conv_first_k, dim3(fp.tiles_x * fp.tiles_y * B), dim3(256), 0, h->stream, fp);
     }));
     auto W_ = [&](int i) -> const ConvW* {
         char k[64];
@@ -345,14 +345,14 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
         return &h->conv[k];
     };
     ConvCall c;
-    c = ConvCall{&e.c11, &e.p1, W_(1), H, W}; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
-    c = ConvCall{&e.p1, &e.c21, W_(2), H / 2, W / 2}; c.epi = E_RELU; RCHK(conv(h, c));
-    c = ConvCall{&e.c21, &e.p2, W_(3), H / 2, W / 2}; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
-    c = ConvCall{&e.p2, &e.c31, W_(4), e.p2.H, e.p2.W}; c.epi = E_RELU; RCHK(conv(h, c));
-    c = ConvCall{&e.c31, &e.c32, W_(5), e.p2.H, e.p2.W}; c.epi = E_RELU; RCHK(conv(h, c));
-    c = ConvCall{&e.c32, &e.c33, W_(6), e.p2.H, e.p2.W}; c.epi = E_RELU; RCHK(conv(h, c));
-    c = ConvCall{&e.c33, &e.p3, W_(7), e.p2.H, e.p2.W}; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
-    c = ConvCall{&e.p3, &e.c41, W_(8), e.p3.H, e.p3.W}; c.epi = E_RELU | (norm0 ? E_NORM1 : 0); c.n1 = norm0; RCHK(conv(h, c));
+    c = ConvCall{&e.c11, &e.p1, W_(1), H, W}; c.B = B; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
+    c = ConvCall{&e.p1, &e.c21, W_(2), H / 2, W / 2}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
+    c = ConvCall{&e.c21, &e.p2, W_(3), H / 2, W / 2}; c.B = B; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
+    c = ConvCall{&e.p2, &e.c31, W_(4), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
+    c = ConvCall{&e.c31, &e.c32, W_(5), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
+    c = ConvCall{&e.c32, &e.c33, W_(6), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
+    c = ConvCall{&e.c33, &e.p3, W_(7), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
+    c = ConvCall{&e.p3, &e.c41, W_(8), e.p3.H, e.p3.W}; c.B = B; c.epi = E_RELU | (norm0 ? E_NORM1 : 0); c.n1 = norm0; RCHK(conv(h, c));
     return RRV_OK;
 }
 
@@ -365,25 +365,25 @@ int ensure_u8(rrv_handle h, size_t bytes) {
 }
 
 // ---- per-frame decoder --------------------------------------------------------------------
-int dec_plan(rrv_handle h, DecPlan& d, int H, int W) {
-    if (d.H == H && d.W == W && d.d.p) return RRV_OK;
-    d.H = H; d.W = W;
+int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {
+    if (d.B == B && d.H == H && d.W == W && d.d.p) return RRV_OK;
+    d.B = B; d.H = H; d.W = W;
     const int H8 = H / 8, W8 = W / 8, H4 = H / 4, W4 = W / 4, H2 = H / 2, W2 = W / 2;
-    RCHK(talloc(h, &d.d, 1, H8, W8, 32));
-    RCHK(talloc(h, &d.f1, 1, H8, W8, 512));
-    RCHK(talloc(h, &d.f2, 1, H8, W8, 512));
-    RCHK(talloc(h, &d.f3, 1, H8, W8, 512));
-    RCHK(talloc(h, &d.xs4, 1, H8, W8, 256));
-    RCHK(talloc(h, &d.a4, 1, H4, W4, 256));
-    RCHK(talloc(h, &d.o4, 1, H4, W4, 256));
-    RCHK(talloc(h, &d.xs3, 1, H4, W4, 128));
-    RCHK(talloc(h, &d.a3, 1, H2, W2, 128));
-    RCHK(talloc(h, &d.o3, 1, H2, W2, 128));
-    RCHK(talloc(h, &d.xs2, 1, H2, W2, 64));
-    RCHK(talloc(h, &d.a2, 1, H, W, 64));
-    RCHK(talloc(h, &d.o2, 1, H, W, 64));
+    RCHK(talloc(h, &d.d, B, H8, W8, 32));
+    RCHK(talloc(h, &d.f1, B, H8, W8, 512));
+    RCHK(talloc(h, &d.f2, B, H8, W8, 512));
+    RCHK(talloc(h, &d.f3, B, H8, W8, 512));
+    RCHK(talloc(h, &d.xs4, B, H8, W8, 256));
+    RCHK(talloc(h, &d.a4, B, H4, W4, 256));
+    RCHK(talloc(h, &d.o4, B, H4, W4, 256));
+    RCHK(talloc(h, &d.xs3, B, H4, W4, 128));
+    RCHK(talloc(h, &d.a3, B, H2, W2, 128));
+    RCHK(talloc(h, &d.o3, B, H2, W2, 128));
+    RCHK(talloc(h, &d.xs2, B, H2, W2, 64));
+    RCHK(talloc(h, &d.a2, B, H, W, 64));
+    RCHK(talloc(h, &d.o2, B, H, W, 64));
     if (d.pre) (void)hipFree(d.pre);
-    RCHK(dalloc(h, &d.pre, (size_t)H * W * 3, true));
+    RCHK(dalloc(h, &d.pre, (size_t)B * H * W * 3, true));
     return RRV_OK;
 }
 
@@ -391,20 +391,21 @@ int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens
     const float* st = h->active;
     const std::string p = std::string("Decoder.") + blk;
     ConvCall c;
-    c = ConvCall{&in, &xs, &h->conv[p + ".conv_shortcut"], in.H, in.W}; RCHK(conv(h, c));   // up(conv1x1(x)) == conv1x1(up(x))
-    c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1]; RCHK(conv(h, c));
-    c = ConvCall{&a, &o, &h->conv[p + ".conv2"], a.H, a.W};
+    c = ConvCall{&in, &xs, &h->conv[p + ".conv_shortcut"], in.H, in.W}; c.B = in.B; RCHK(conv(h, c));   // up(conv1x1(x)) == conv1x1(up(x))
+    c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.B = in.B; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1]; RCHK(conv(h, c));
+    c = ConvCall{&a, &o, &h->conv[p + ".conv2"], a.H, a.W}; c.B = in.B;
     c.epi = E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2; c.n1 = st + SL.norm[n2]; c.res = &xs; c.n2 = st + SL.norm[nada]; c.sty = st + SL.sty[sty];
     RCHK(conv(h, c));
     return RRV_OK;
 }
 
-int transfer_device(rrv_handle h, const uint8_t* d_in, int H, int W, float* d_out) {
+int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, float* d_out) {
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
     if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
     if (h->active_src == -1) return fail(h, RRV_E_STATE, "state not computed: call compute() (or set_state) before transfer()");
-    RCHK(enc_plan(h, h->enc_frame, H, W));
-    RCHK(dec_plan(h, h->dec, H, W));
+    if (B < 1 || B > 64) return fail(h, RRV_E_ARG, "transfer: batch must be in 1..64");
+    RCHK(enc_plan(h, h->enc_frame, B, H, W));
+    RCHK(dec_plan(h, h->dec, B, H, W));
     DecPlan& d = h->dec;
     EncPlan& e = h->enc_frame;
     const float* st = h->active;
@@ -412,8 +413,8 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int H, int W, float* d_ou
     const Tens* cur = &e.c41;
     Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
     for (int f = 0; f < 3; ++f) {
-        ConvCall c{cur, &d.d, &h->fold_down[f], cur->H, cur->W}; c.epi = E_LRELU; RCHK(conv(h, c));
-        ConvCall u{&d.d, fo[f], &h->fold_up[f], cur->H, cur->W};
+        ConvCall c{cur, &d.d, &h->fold_down[f], cur->H, cur->W}; c.B = B; c.epi = E_LRELU; RCHK(conv(h, c));
+        ConvCall u{&d.d, fo[f], &h->fold_up[f], cur->H, cur->W}; u.B = B;
         u.epi = E_RES | (f == 2 ? E_NORM2 : 0); u.res = cur;
         if (f == 2) { u.n2 = st + SL.norm[N_DEC1]; u.sty = st + SL.sty[3]; }
         RCHK(conv(h, u));
@@ -422,9 +423,9 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int H, int W, float* d_ou
     RCHK(resblock_frame(h, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2));
     RCHK(resblock_frame(h, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1));
     RCHK(resblock_frame(h, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0));
-    LastP lp{d.o2.p, H, W, h->last_w, h->last_b, d_out, d.pre, (W + 15) / 16, (H + 15) / 16};
-    RCHK(launch(h, "conv_last", 2.0 * H * W * 576 * 3, 256.0 * H * W + 12.0 * H * W, [&] {
-        hipLaunchKernelGGL(conv_last_k, dim3(lp.tiles_x * lp.tiles_y), dim3(256), 0, h->stream, lp);
+    LastP lp{d.o2.p, H, W, B, h->last_w, h->last_b, d_out, d.pre, (W + 15) / 16, (H + 15) / 16};
+    RCHK(launch(h, "conv_last", 2.0 * B * H * W * 576 * 3, (256.0 + 12.0) * B * H * W, [&] {
+        hipLaunchKernelGGL(conv_last_k, dim3(lp.tiles_x * lp.tiles_y * B), dim3(256), 0, h->stream, lp);
     }));
     return RRV_OK;
 }
@@ -648,7 +649,7 @@ int rrv_prepare_style(rrv_handle h, const uint8_t* style, int Hs, int Ws, int si
     if (!S.blob) RCHK(dalloc(h, &S.blob, RRV_STATE_FLOATS));
     RCHK(ensure_u8(h, (size_t)Hs * Ws * 3));
     HIPCHK(hipMemcpyAsync(h->d_u8, style, (size_t)Hs * Ws * 3, hipMemcpyHostToDevice, h->stream));
-    RCHK(enc_plan(h, h->enc_style, Hs, Ws));
+    RCHK(enc_plan(h, h->enc_style, 1, Hs, Ws));
     EncPlan& e = h->enc_style;
     RCHK(run_encoder(h, e, h->d_u8, 1, nullptr));
     // cal_mean_std at relu1_1..relu4_1 (style_network_global.py:304-331)
@@ -682,7 +683,7 @@ int rrv_add(rrv_handle h, const uint8_t* frame, int H, int W) {
         return fail(h, RRV_E_ARG, "add: all sampled frames must have the same size");
     RCHK(ensure_u8(h, (size_t)H * W * 3));
     HIPCHK(hipMemcpyAsync(h->d_u8, frame, (size_t)H * W * 3, hipMemcpyHostToDevice, h->stream));
-    RCHK(enc_plan(h, h->enc_add, H, W));
+    RCHK(enc_plan(h, h->enc_add, 1, H, W));
     RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr));
     const Tens& f = h->enc_add.c41;
     float* keep = nullptr;
@@ -740,7 +741,7 @@ int rrv_set_state(rrv_handle h, const float* in, int n, int sid) {
     return RRV_OK;
 }
 
-int rrv_transfer_device(rrv_handle h, const void* d_in, int H, int W, void* d_out) {
+int rrv_transfer_batch_device(rrv_handle h, const void* d_in, int B, int H, int W, void* d_out) {
     if (!h || !d_in || !d_out) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     if (h->active_src == -2) h->active_src = -1;
@@ -748,7 +749,11 @@ int rrv_transfer_device(rrv_handle h, const void* d_in, int H, int W, void* d_ou
         for (int s = 0; s < RRV_MAX_STYLES; ++s)
             if (h->styles[s].computed) { RCHK(activate_state(h, s)); break; }
     }
-    return transfer_device(h, (const uint8_t*)d_in, H, W, (float*)d_out);
+    return transfer_device(h, (const uint8_t*)d_in, B, H, W, (float*)d_out);
+}
+
+int rrv_transfer_device(rrv_handle h, const void* d_in, int H, int W, void* d_out) {
+    return rrv_transfer_batch_device(h, d_in, 1, H, W, d_out);
 }
 
 int rrv_transfer_blend_device(rrv_handle h, const void* d_in, int H, int W, const float* wts, int ns, void* d_out) {
@@ -764,29 +769,45 @@ int rrv_transfer_blend_device(rrv_handle h, const void* d_in, int H, int W, cons
     HIPCHK(hipGetLastError());
     for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
     h->active_src = -2;
-    return transfer_device(h, (const uint8_t*)d_in, H, W, (float*)d_out);
+    return transfer_device(h, (const uint8_t*)d_in, 1, H, W, (float*)d_out);
 }
 
-int rrv_transfer(rrv_handle h, const uint8_t* frame, int H, int W, float* out) {
-    if (!h || !frame || !out) return RRV_E_ARG;
+// host-buffer wrappers: H2D, same device path, D2H
+static int host_roundtrip(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out, const float* wts, int ns) {
+    if (!h || !frames || !out || B < 1) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
-    const size_t n = (size_t)H * W * 3;
+    const size_t n = (size_t)B * H * W * 3;
     RCHK(ensure_u8(h, n));
     if (h->d_outf_cap < n) {
         if (h->d_outf) (void)hipFree(h->d_outf);
+        h->d_outf = nullptr; h->d_outf_cap = 0;
         HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
         h->d_outf_cap = n;
     }
-    HIPCHK(hipMemcpyAsync(h->d_u8, frame, n, hipMemcpyHostToDevice, h->stream));
-    RCHK(rrv_transfer_device(h, h->d_u8, H, W, h->d_outf));
+    HIPCHK(hipMemcpyAsync(h->d_u8, frames, n, hipMemcpyHostToDevice, h->stream));
+    if (wts) RCHK(rrv_transfer_blend_device(h, h->d_u8, H, W, wts, ns, h->d_outf));
+    else RCHK(rrv_transfer_batch_device(h, h->d_u8, B, H, W, h->d_outf));
     HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return RRV_OK;
 }
 
+int rrv_transfer(rrv_handle h, const uint8_t* frame, int H, int W, float* out) {
+    return host_roundtrip(h, frame, 1, H, W, out, nullptr, 0);
+}
+
+int rrv_transfer_batch(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out) {
+    return host_roundtrip(h, frames, B, H, W, out, nullptr, 0);
+}
+
+int rrv_transfer_blend(rrv_handle h, const uint8_t* frame, int H, int W, const float* wts, int ns, float* out) {
+    if (!wts) return RRV_E_ARG;
+    return host_roundtrip(h, frame, 1, H, W, out, wts, ns);
+}
+
 int rrv_get_preclamp(rrv_handle h, float* out, int H, int W) {
     if (!h || !out) return RRV_E_ARG;
-    if (!h->dec.pre || h->dec.H != H || h->dec.W != W) return fail(h, RRV_E_STATE, "get_preclamp: no transfer of that size yet");
+    if (!h->dec.pre || h->dec.H != H || h->dec.W != W || h->dec.B < 1) return fail(h, RRV_E_STATE, "get_preclamp: no transfer of that size yet");
     HIPCHK(hipSetDevice(h->dev));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->dec.pre, (size_t)H * W * 3 * sizeof(float), hipMemcpyDeviceToHost));

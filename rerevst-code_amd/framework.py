@@ -105,19 +105,26 @@ class Stylization():
         if style_weight is None:
             self._chk(self._lib.rrv_transfer(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p)))
             return out
-        import torch  # plumbing: device buffers for the blend entry point
-        dev = torch.device("cuda", self.device)
-        d_in = torch.from_numpy(a).to(dev)
-        d_out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-        torch.cuda.synchronize(dev)
         w = (C.c_float * len(style_weight))(*[float(v) for v in style_weight])
-        self._chk(self._lib.rrv_transfer_blend_device(self._h, d_in.data_ptr(), H, W, w, len(style_weight), d_out.data_ptr()))
-        self.sync()
-        return d_out.cpu().numpy()
+        self._chk(self._lib.rrv_transfer_blend(self._h, a.ctypes.data_as(C.c_void_p), H, W, w, len(style_weight),
+                                               out.ctypes.data_as(C.c_void_p)))
+        return out
 
     # ===== device-resident entry (what bench.py times) =====
     def transfer_device(self, d_in_ptr, H, W, d_out_ptr):
         self._chk(self._lib.rrv_transfer_device(self._h, C.c_void_p(d_in_ptr), H, W, C.c_void_p(d_out_ptr)))
+
+    def transfer_batch_device(self, d_in_ptr, B, H, W, d_out_ptr):
+        """[B][H][W][3] uint8 in HBM -> [B][H][W][3] float32 in HBM, asynchronous on the library stream."""
+        self._chk(self._lib.rrv_transfer_batch_device(self._h, C.c_void_p(d_in_ptr), B, H, W, C.c_void_p(d_out_ptr)))
+
+    def transfer_batch(self, frames):
+        """Stylize a list of equally sized uint8 BGR frames in one launch sequence."""
+        a = np.stack([_u8_image(f, "frame") for f in frames])
+        B, H, W, _ = a.shape
+        out = np.empty((B, H, W, 3), dtype=np.float32)
+        self._chk(self._lib.rrv_transfer_batch(self._h, a.ctypes.data_as(C.c_void_p), B, H, W, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def sync(self):
         self._chk(self._lib.rrv_sync(self._h))

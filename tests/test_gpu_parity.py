@@ -56,3 +56,16 @@ def test_transfer_before_compute_is_an_error(pkg, weights):
     with pytest.raises(pkg.RRVError, match="state not computed"):
         s.transfer(np.zeros((64, 64, 3), np.uint8))
     s.close()
+
+
+def test_batched_transfer_equals_per_frame(hip, pkg, oracle):
+    """rrv_transfer_batch_device over B frames == B single-frame transfers (same arithmetic per frame)."""
+    g = load_golden("global_a")
+    _, frames, _, _ = golden_inputs(pkg, g)
+    hip.set_state(g["state"])
+    padded = [oracle.reflect_pad(f, 192, 192) for f in frames[:3]]
+    single = [hip.transfer(p) for p in padded]
+    batch = hip.transfer_batch(padded)
+    assert batch.shape == (3, 192, 192, 3)
+    for k in range(3):
+        np.testing.assert_array_equal(batch[k], single[k])
