@@ -339,6 +339,63 @@ class Stylization:
             o += 2 * C
 
 
+class MultiStylization:
+    """Mirror of "Multi-style Interpolation/stylization.py":42-100 (S styles, per-frame
+    weight vector).  Per style the preparation pass is the single-style one
+    (style_network.py:415-430); per frame every saved quantity q is replaced by
+    sum_s w_s q_s (:35-53 mean/rstd/min/max, :135-139 filters, :348-360 style moments)
+    before the same decoder forward (:432-460).  The encoder runs in
+    generate_content_features and its output is what add_patch / transfer receive."""
+
+    def __init__(self, weights, style_num=1):
+        self.net = Net(weights)
+        self.style_num = style_num
+        self.per_style = [Stylization(weights) for _ in range(style_num)]
+        for p in self.per_style:
+            p.net = self.net
+            p.dec.net = self.net
+        self.F_patches = []
+
+    def prepare_style(self, style_images):          # stylization.py:71-79
+        for sid, img in enumerate(style_images):
+            self.per_style[sid].prepare_style(img)
+
+    def generate_content_features(self, content):   # stylization.py:87-92
+        return self.net.encoder(rgb2gray(image_to_tensor(content)))
+
+    def add_patch(self, feature):                   # stylization.py:66-67
+        self.F_patches.append(feature)
+
+    def compute_norm(self):                         # stylization.py:81-83, style_network.py:498-500
+        x = np.concatenate(self.F_patches, axis=0)
+        for p in self.per_style:
+            p.dec.run(x, p.F_style, compute=True)
+        self.F_patches = []
+
+    def clean(self):                                # stylization.py:85
+        for p in self.per_style:
+            p.dec.clean()
+
+    def get_state(self, style_id):
+        return self.per_style[style_id].get_state()
+
+    def transfer(self, feature, style_weight=(1.0,), return_preclamp=False):   # stylization.py:94-100
+        blob = np.zeros(STATE_FLOATS, dtype=F32)
+        for sid in range(self.style_num):
+            blob = blob + self.per_style[sid].get_state() * F32(style_weight[sid])
+        tmp = Stylization({})
+        tmp.net, tmp.dec.net = self.net, self.net
+        tmp.set_state(blob.astype(F32))
+        y = tmp.dec.run(feature, tmp.F_style, compute=False)
+        return y if return_preclamp else tensor_to_image(y)
+
+
+def sample_indices_multistyle(n, interval=16):
+    """VideoStylization.SeqNormPrePare ("Multi-style Interpolation/test.py":72-85): frames
+    s*16 for s < (n-1)//16+1, then the last frame (again, if it was already sampled)."""
+    return [s * interval for s in range((n - 1) // interval + 1)] + [n - 1]
+
+
 # ---- driver-side helpers (test/generate_real_video.py) ----------------------------------
 
 def padded_size(n):

@@ -128,12 +128,69 @@ def run_case(name, weights, style_hw, frame_hw, n_frames, sample_ids, transfer_i
     np.savez(os.path.join(HERE, name + ".npz"), **g)
 
 
+def run_multistyle(name, weights):
+    """S=2 multi-style interpolation ("Multi-style Interpolation/"): per-style state blobs and
+    one blended transfer with weights [0.3, 0.7]."""
+    sty_mod, net_mod = R.import_reference("Multi-style Interpolation", "stylization", "style_network")
+    S = 2
+    s = sty_mod.Stylization.__new__(sty_mod.Stylization)
+    s.device = torch.device("cpu")
+    s.transformer = net_mod.TransformerNet(style_num=S)
+    new = {}
+    for k, v in s.transformer.state_dict().items():
+        new[k] = torch.from_numpy(weights[k].copy()) if k in weights else torch.zeros_like(v)
+        assert k in weights or k.startswith("Vgg19."), k
+    s.transformer.load_state_dict(new, strict=True)
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7), pkg.synth_style(64, 64, kind="smooth", seed=8)]
+    frames = [pkg.synth_frame(i, 64, 48, kind="smooth") for i in range(3)]
+    padded = [O.reflect_pad(f, 192, 192) for f in frames]
+    s.prepare_style(styles)
+    feats = [s.generate_content_features(p.copy()) for p in padded]     # padded BEFORE encoding (test.py:96)
+    s.clean()
+    for i in (0, 2):
+        s.add_patch(feats[i])
+    s.compute_norm()
+    wts = [0.3, 0.7]
+    out = s.transfer(feats[1], wts)
+    with torch.no_grad():
+        pre = nhwc(s.transformer(feats[1], wts))[0]
+    d = s.transformer.Decoder
+    norms = list(d.norm) + [d.slice4.norm1, d.slice4.norm2, d.slice3.norm1, d.slice3.norm2, d.slice2.norm1, d.slice2.norm2]
+    blobs = []
+    for sid in range(S):
+        parts = []
+        for n in norms:
+            for t in (n.saved_mean[sid], n.saved_std[sid], n.x_min[sid], n.x_max[sid]):
+                parts.append(t.reshape(-1).numpy())
+        for f in (d.Filter1, d.Filter2, d.Filter3):
+            for g in (f.F1, f.F2):
+                parts.append(g.filter[sid].reshape(-1).numpy())
+        for k, nm in enumerate(O.STYLE_NAMES):
+            ms = getattr(s.transformer.F_style[sid], nm)
+            parts += [ms.mean.reshape(-1).numpy(), ms.std.reshape(-1).numpy()]
+        blobs.append(np.concatenate(parts).astype(np.float32))
+    o = O.MultiStylization(weights, S)
+    o.prepare_style(styles)
+    of = [o.generate_content_features(p) for p in padded]
+    o.clean()
+    for i in (0, 2):
+        o.add_patch(of[i])
+    o.compute_norm()
+    opre = o.transfer(of[1], wts, return_preclamp=True)[0]
+    print("[%s] state rel err max %.3e / %.3e | pre-clamp max|d| %.3e (std %.3f) | image max|d| %.4f"
+          % (name, *(float((np.abs(o.get_state(i) - blobs[i]) / (np.abs(blobs[i]) + 1e-3)).max()) for i in range(2)),
+             np.abs(opre - pre).max(), pre.std(), np.abs(o.transfer(of[1], wts) - out).max()))
+    np.savez(os.path.join(HERE, name + ".npz"), state0=blobs[0], state1=blobs[1], weights=np.array(wts, np.float32),
+             pre_crop=pre[64:128, 64:112].astype(np.float32), out_crop=out[64:128, 64:112].astype(np.float32))
+
+
 def main():
     w = pkg.synthetic_weights(0)
     # A: 3 sampled frames (Q1,Q3,Q4), transfer of a NON-sampled frame, full padded output
     run_case("global_a", w, (64, 64), (64, 48), 4, [0, 1, 3], 2, crop_only=False)
     # B: frame sides not multiples of 8 (pool floors in add), P=256x192, cropped output only
     run_case("global_b", w, (72, 56), (90, 50), 3, [0, 2], 1, crop_only=True)
+    run_multistyle("multistyle_s2", w)
 
 
 if __name__ == "__main__":

@@ -69,3 +69,27 @@ def test_batched_transfer_equals_per_frame(hip, pkg, oracle):
     assert batch.shape == (3, 192, 192, 3)
     for k in range(3):
         np.testing.assert_array_equal(batch[k], single[k])
+
+
+def test_multistyle_blend_matches_reference(pkg, weights, oracle):
+    """Config-5 path: two styles prepared, per-style state, blended transfer (weights .3/.7)."""
+    g = load_golden("multistyle_s2")
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7), pkg.synth_style(64, 64, kind="smooth", seed=8)]
+    frames = [pkg.synth_frame(i, 64, 48, kind="smooth") for i in range(3)]
+    padded = [oracle.reflect_pad(f, 192, 192) for f in frames]
+    s = pkg.Stylization(weights, cuda=True, style_num=2)
+    s.prepare_style(styles)
+    s.clean()
+    for i in (0, 2):
+        s.add(padded[i])          # multi-style pads BEFORE encoding ("Multi-style Interpolation/test.py":96)
+    s.compute()
+    assert_state_close(s.get_state(0), g["state0"], "style 0")
+    assert_state_close(s.get_state(1), g["state1"], "style 1")
+    out = s.transfer(padded[1], style_weight=[float(v) for v in g["weights"]])
+    assert_pre_close(s.preclamp(192, 192)[64:128, 64:112], g["pre_crop"])
+    assert np.abs(out[64:128, 64:112] - g["out_crop"]).max() <= IMG_ATOL
+    # a plain transfer afterwards falls back to style 0's own state
+    one = s.transfer(padded[1])
+    s2 = s.transfer(padded[1], style_weight=[1.0, 0.0])
+    assert np.abs(one - s2).max() <= 1e-3
+    s.close()

@@ -70,3 +70,25 @@ def test_driver_helpers(oracle):
     p = oracle.reflect_pad(img, 192, 192)
     assert p.shape == (192, 192, 3)
     assert (p[63] == p[64]).all() and (p[:, 63] == p[:, 64]).all()   # edge-inclusive reflect
+
+
+def test_multistyle_blend_matches_reference(oracle, pkg, weights):
+    """S=2 "Multi-style Interpolation" path: per-style blobs + one blended transfer."""
+    g = load_golden("multistyle_s2")
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7), pkg.synth_style(64, 64, kind="smooth", seed=8)]
+    frames = [pkg.synth_frame(i, 64, 48, kind="smooth") for i in range(3)]
+    padded = [oracle.reflect_pad(f, 192, 192) for f in frames]
+    o = oracle.MultiStylization(weights, 2)
+    o.prepare_style(styles)
+    feats = [o.generate_content_features(p) for p in padded]
+    o.clean()
+    for i in (0, 2):
+        o.add_patch(feats[i])
+    o.compute_norm()
+    assert_state_close(o.get_state(0), g["state0"], "style 0")
+    assert_state_close(o.get_state(1), g["state1"], "style 1")
+    wts = [float(v) for v in g["weights"]]
+    pre = o.transfer(feats[1], wts, return_preclamp=True)[0][64:128, 64:112]
+    assert_pre_close(pre, g["pre_crop"])
+    assert np.abs(o.transfer(feats[1], wts)[64:128, 64:112] - g["out_crop"]).max() <= IMG_ATOL
+    assert oracle.sample_indices_multistyle(33) == [0, 16, 32, 32]
