@@ -41,6 +41,7 @@ struct Tens {
 struct ConvW {           // one convolution's device weights
     float* raw = nullptr;    // OIHW as in the checkpoint
     float* pk = nullptr;     // kernel-native packed
+    float* pk_ups = nullptr; // parity-folded pack for conv_ups2_k (convs that follow a nearest-x2 upsample)
     float* bias = nullptr;   // [Cout] (zeros for bias-free convs)
     int Cout = 0, Cin = 0, taps = 0, BN = 0;
 };
@@ -171,18 +172,29 @@ const ConvKey CONV_TABLE[] = {
     CK(32, 9, 0, E_LRELU), CK(128, 9, 0, E_RES), CK(128, 9, 0, E_RES | E_NORM2),
     // residual blocks, per-frame
     CK(128, 1, 0, 0), CK(64, 1, 0, 0),
-    CK(128, 9, 1, E_LRELU | E_NORM1), CK(64, 9, 1, E_LRELU | E_NORM1),
     CK(128, 9, 0, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), CK(64, 9, 0, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2),
     // preparation pass (raw outputs, statistics taken afterwards)
-    CK(32, 9, 0, 0), CK(128, 9, 0, 0), CK(128, 9, 1, E_LRELU), CK(64, 9, 1, E_LRELU),
+    CK(32, 9, 0, 0), CK(128, 9, 0, 0),
     CK(128, 9, 0, E_LRELU), CK(64, 9, 0, E_LRELU),
 };
+
+template <int BN, int EPI>
+void ups2_launch(const ConvP& p, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_ups2_k<BN, EPI>), grid, dim3(256), 0, s, p);
+}
+#define UK(BN, EPI) {BN, 9, 1, EPI, &ups2_launch<BN, EPI>, "conv_ups2<" #BN "," #EPI ">"}
+const ConvKey UPS_TABLE[] = {UK(128, E_LRELU | E_NORM1), UK(64, E_LRELU | E_NORM1), UK(128, E_LRELU), UK(64, E_LRELU)};
 
 int conv(rrv_handle h, const ConvCall& c) {
     const ConvW& w = *c.w;
     const ConvKey* k = nullptr;
-    for (const ConvKey& e : CONV_TABLE)
-        if (e.BN == w.BN && e.TAPS == w.taps && e.UPS == (int)c.ups && e.EPI == c.epi) { k = &e; break; }
+    if (c.ups) {
+        for (const ConvKey& e : UPS_TABLE)
+            if (e.BN == w.BN && e.EPI == c.epi) { k = &e; break; }
+    } else {
+        for (const ConvKey& e : CONV_TABLE)
+            if (e.BN == w.BN && e.TAPS == w.taps && e.EPI == c.epi) { k = &e; break; }
+    }
     if (!k) {
         char b[128];
         snprintf(b, sizeof b, "no conv kernel for BN=%d taps=%d ups=%d epi=%d", w.BN, w.taps, (int)c.ups, c.epi);
@@ -192,7 +204,8 @@ int conv(rrv_handle h, const ConvCall& c) {
     p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W; p.Cin = w.Cin;
     p.out = c.out->p; p.H = c.H; p.W = c.W; p.Cout = w.Cout; p.B = c.B;
     p.in_bstride0 = 1;
-    p.wpk = w.pk; p.bias = w.bias; p.n1 = c.n1; p.n2 = c.n2; p.sty = c.sty;
+    p.wpk = c.ups ? w.pk_ups : w.pk; p.bias = w.bias;
+    if (!p.wpk) return fail(h, RRV_E_ARG, "conv: weights not packed for this kernel"); p.n1 = c.n1; p.n2 = c.n2; p.sty = c.sty;
     if (c.res) { p.res = c.res->p; p.Hr = c.res->H; p.Wr = c.res->W; }
     p.tiles_x = (c.W + 15) / 16; p.tiles_y = (c.H + 7) / 8;
     if (c.in->C != w.Cin || c.out->C != w.Cout) return fail(h, RRV_E_ARG, "conv: channel mismatch");
@@ -200,9 +213,10 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (c.in->H != eh || c.in->W != ew) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
     if (c.out->H != oh || c.out->W != ow) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B), (unsigned)(w.Cout / w.BN));
+    if (c.ups) { p.tiles_y = (c.H + 15) / 16; }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B * (c.ups ? 2 : 1)), (unsigned)(w.Cout / w.BN));
     const double px = (double)c.B * c.H * c.W;
-    const double flops = 2.0 * px * w.Cout * w.Cin * w.taps;
+    const double flops = 2.0 * px * w.Cout * w.Cin * (c.ups ? 4 : w.taps);   // executed MACs (ups2 folds 9 taps into 4)
     const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * w.Cin + (double)c.B * oh * ow * w.Cout +
                                 (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps);
     hipStream_t s = h->stream;
@@ -230,6 +244,14 @@ int pack(rrv_handle h, ConvW& w) {
 }
 
 int bn_for(int cout) { return cout >= 128 ? 128 : (cout >= 64 ? 64 : 32); }
+
+int pack_ups(rrv_handle h, ConvW& w) {
+    const size_t total = (size_t)w.Cout * w.Cin * 16;
+    if (!w.pk_ups) RCHK(dalloc(h, &w.pk_ups, total, false));
+    hipLaunchKernelGGL(pack_ups2_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_ups, w.Cout, w.Cin, w.BN);
+    HIPCHK(hipGetLastError());
+    return RRV_OK;
+}
 
 int make_conv(rrv_handle h, const std::string& prefix, int cout, int cin, int taps, bool has_bias, bool do_pack = true) {
     ConvW w;
@@ -543,7 +565,11 @@ int rrv_destroy(rrv_handle h) {
     (void)hipSetDevice(h->dev);
     (void)hipDeviceSynchronize();
     // device memory is released with the process / context; free the big pieces explicitly
-    for (auto& kv : h->conv) { if (kv.second.raw) (void)hipFree(kv.second.raw); if (kv.second.pk) (void)hipFree(kv.second.pk); }
+    for (auto& kv : h->conv) {
+        if (kv.second.raw) (void)hipFree(kv.second.raw);
+        if (kv.second.pk) (void)hipFree(kv.second.pk);
+        if (kv.second.pk_ups) (void)hipFree(kv.second.pk_ups);
+    }
     for (float* p : h->patches) (void)hipFree(p);
     for (EncPlan* e : {&h->enc_frame, &h->enc_add, &h->enc_style})
         for (Tens* t : {&e->c11, &e->p1, &e->c21, &e->p2, &e->c31, &e->c32, &e->c33, &e->p3, &e->c41}) tfree(t);
@@ -598,7 +624,8 @@ int rrv_finalize_weights(rrv_handle h) {
     const char* bn[3] = {"slice4", "slice3", "slice2"};
     for (int b = 0; b < 3; ++b) {
         const std::string p = std::string("Decoder.") + bn[b];
-        RCHK(make_conv(h, p + ".conv1", bc[b][1], bc[b][0], 9, true));
+        RCHK(make_conv(h, p + ".conv1", bc[b][1], bc[b][0], 9, true, false));
+        RCHK(pack_ups(h, h->conv[p + ".conv1"]));
         RCHK(make_conv(h, p + ".conv2", bc[b][1], bc[b][1], 9, true));
         RCHK(make_conv(h, p + ".conv_shortcut", bc[b][1], bc[b][0], 1, false));
     }
