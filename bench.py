@@ -44,13 +44,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RRV_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a 1-GPU box (all ranks on GPU 0)
+    backend = os.environ.get("RRV_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective payloads live
 
     pkg = importlib.import_module("rerevst-code_amd")
     video = importlib.import_module("rerevst-code_amd.video")
@@ -72,7 +77,7 @@ def main():
 
     # ---- once-per-video preparation on rank 0, state broadcast over RCCL ------------------
     t0 = time.time()
-    blob = torch.empty(17536, dtype=torch.float32, device=dev)
+    blob = torch.empty(17536, dtype=torch.float32, device=cdev)
     if rank == 0:
         model.prepare_style(pkg.synth_style(512, 512, kind="noise", seed=7))
         model.clean()
@@ -112,7 +117,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -75,7 +75,9 @@ __device__ __forceinline__ void glds16(const float* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, int TAPS, bool UPS, int EPI>
+// ABL is for tools/conv_microbench.hip only (ablations: 1 = no loads after the first stage,
+// 2 = no barriers, 4 = no stores); the library always instantiates ABL = 0.
+template <int BN, int TAPS, bool UPS, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
     using WC = WaveCfg<BN>;
     constexpr int HWD = (TAPS == 1) ? 16 : (UPS ? 10 : 18);   // halo tile width  (pixels)
@@ -158,11 +160,13 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
         const char* abuf = smem + (chunk & 1) * A_BYTES;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap, ++step) {
-            __syncthreads();   // drains this wave's LDS-DMA (vmcnt 0) and publishes step's tiles
-            if (tap + 1 < TAPS)
-                stage(chunk, tap + 1, step + 1);
-            else if (chunk + 1 < nchunks)
-                stage(chunk + 1, 0, step + 1);
+            if (!(ABL & 2) || step == 0) __syncthreads();   // drains this wave's LDS-DMA (vmcnt 0), publishes step's tiles
+            if (!(ABL & 1)) {
+                if (tap + 1 < TAPS)
+                    stage(chunk, tap + 1, step + 1);
+                else if (chunk + 1 < nchunks)
+                    stage(chunk + 1, 0, step + 1);
+            }
             const char* bbuf = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
             const int ky = tap / 3, kx = tap - ky * 3;
             int offA[WC::WM_SUB];
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int y = y0 + 2 * msg + (i >> 4), x = x0 + (i & 15);
+                    if (ABL & 4) { if (v[r] == 123.456f) out_b[co] = v[r]; continue; }
                     if (y < p.H && x < p.W) out_b[((y + 1) * (p.W + 2) + x + 1) * p.Cout + co] = v[r];
                 }
             }

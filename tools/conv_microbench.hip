@@ -1,0 +1,60 @@
+// tools/conv_microbench.hip — standalone timing of conv_mfma_k variants on one layer shape.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_microbench.hip -o gpurun_out/conv_microbench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../rerevst-code_amd/csrc/conv_mfma.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int BN, int TAPS, int EPI, int ABL>
+float run(const ConvP& p, int iters) {
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / BN);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, false, EPI, ABL>), grid, dim3(256), 0, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, false, EPI, ABL>), grid, dim3(256), 0, 0, p);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+template <int BN>
+void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
+    const size_t in_f = (size_t)B * (H + 2) * (W + 2) * Cin + (size_t)20 * (W + 22) * Cin;
+    const size_t out_f = (size_t)B * (H + 2) * (W + 2) * Cout + (size_t)20 * (W + 22) * Cout;
+    float *in, *out, *w, *bias;
+    CK(hipMalloc(&in, in_f * 4)); CK(hipMalloc(&out, out_f * 4));
+    CK(hipMalloc(&w, (size_t)Cout * Cin * 9 * 4)); CK(hipMalloc(&bias, Cout * 4));
+    std::vector<float> hin(in_f), hw((size_t)Cout * Cin * 9);
+    for (auto& v : hin) v = (rand() / (float)RAND_MAX) - 0.5f;
+    for (auto& v : hw) v = ((rand() / (float)RAND_MAX) - 0.5f) * 0.05f;
+    CK(hipMemcpy(in, hin.data(), in_f * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, Cout * 4)); CK(hipMemset(out, 0, out_f * 4));
+    ConvP p{};
+    p.in = in; p.Hi = H; p.Wi = W; p.Cin = Cin; p.out = out; p.H = H; p.W = W; p.Cout = Cout; p.B = B; p.in_bstride0 = 1;
+    p.wpk = w; p.bias = bias; p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
+    const double fl = 2.0 * B * H * W * (double)Cin * Cout * 9;
+    const int it = 10;
+    float t0 = run<BN, 9, E_RELU, 0>(p, it), t1 = run<BN, 9, E_RELU, 1>(p, it), t2 = run<BN, 9, E_RELU, 2>(p, it),
+          t3 = run<BN, 9, E_RELU, 3>(p, it), t4 = run<BN, 9, E_RELU, 4>(p, it), t7 = run<BN, 9, E_RELU, 7>(p, it);
+    printf("%-28s base %.3f ms %.1f TF | noload %.1f | nobarrier %.1f | noload+nobar %.1f | nostore %.1f | none %.1f TF  (WGs=%d)\n", name, t0,
+           fl / t0 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9, fl / t3 / 1e9, fl / t4 / 1e9, fl / t7 / 1e9,
+           p.tiles_x * p.tiles_y * B * (Cout / BN));
+    CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));
+}
+
+int main() {
+    layer<128>("256->256 @160^2 B8", 8, 160, 160, 256, 256);
+    layer<128>("128->128 @320^2 B8", 8, 320, 320, 128, 128);
+    layer<64>("64->64 @640^2 B8", 8, 640, 640, 64, 64);
+    layer<128>("256->256 @160^2 B1", 1, 160, 160, 256, 256);
+    layer<128>("256->512 @80^2 B8", 8, 80, 80, 256, 512);
+    return 0;
+}
