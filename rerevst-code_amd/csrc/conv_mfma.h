@@ -75,13 +75,26 @@ __device__ __forceinline__ void glds16(const float* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// buffer_load_dwordx4 ... lds: wave-uniform base in an SGPR descriptor, 32-bit per-lane byte offset
+// (voff) plus a scalar byte offset (soff).  Device pass only (the descriptor type has no host form).
+__device__ __forceinline__ void bufld16(const void* base, char* lds_wave_base, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+#endif
+}
+
 // ABL is for tools/conv_microbench.hip only (ablations: 1 = no loads after the first stage,
 // 2 = no barriers, 4 = no stores); the library always instantiates ABL = 0.
-template <int BN, int TAPS, bool UPS, int EPI, int ABL = 0>
+// MSUB overrides the number of M-subtiles per wave (tile rows = WAVES_M * MSUB * 2); LD selects the
+// LDS-DMA flavour (0: global_load_lds, 1: buffer_load ... lds with a wave-uniform descriptor).
+template <int BN, int TAPS, bool UPS, int EPI, int ABL = 0, int MSUB = 0, int LD = 1>
 __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
     using WC = WaveCfg<BN>;
+    constexpr int WM_SUB = MSUB ? MSUB : WC::WM_SUB;
+    constexpr int TROWS = WC::WAVES_M * WM_SUB * 2;             // output tile rows (x 16 cols)
     constexpr int HWD = (TAPS == 1) ? 16 : (UPS ? 10 : 18);   // halo tile width  (pixels)
-    constexpr int HHT = (TAPS == 1) ? 8 : (UPS ? 6 : 10);     // halo tile height (pixels)
+    constexpr int HHT = (TAPS == 1) ? TROWS : (UPS ? TROWS / 2 + 2 : TROWS + 2);   // halo tile height
     constexpr int NPIX = HHT * HWD;
     constexpr int A_ITERS = (NPIX * 4 + 255) / 256;
     constexpr int A_BYTES = A_ITERS * 256 * 16;
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
     const int ty = bx % p.tiles_y;
     const int b = bx / p.tiles_y;
     const int n_tile = blockIdx.y;
-    const int y0 = ty * 8, x0 = tx * 16;
+    const int y0 = ty * TROWS, x0 = tx * 16;
     const int nchunks = p.Cin >> 4;
 
     // ---- per-lane global source offsets of the A (halo) pieces; chunk base added later
@@ -119,19 +132,29 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
     }
     const float* wsrc = p.wpk + (size_t)n_tile * nchunks * TAPS * (BN * 16) + tid * 4;
 
+    const float* w_tile = p.wpk + (size_t)n_tile * nchunks * TAPS * (BN * 16);
     auto stage = [&](int chunk, int tap, int step) {
         char* bdst = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
         const float* wb = wsrc + (size_t)(chunk * TAPS + tap) * (BN * 16);
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
-            if (B_PIECES >= 256 || wave * 64 < B_PIECES)
-                glds16(wb + it * 1024, bdst + (it * 256 + wave * 64) * 16);
+            if (B_PIECES >= 256 || wave * 64 < B_PIECES) {
+                if (LD == 1)
+                    bufld16(w_tile, bdst + (it * 256 + wave * 64) * 16, tid * 16 + it * 4096, (chunk * TAPS + tap) * (BN * 64));
+                else
+                    glds16(wb + it * 1024, bdst + (it * 256 + wave * 64) * 16);
+            }
         }
         if (tap == 0) {
             char* adst = smem + (chunk & 1) * A_BYTES;
             const float* ab = in_b + chunk * 16;
 #pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) glds16(ab + asrc[it], adst + (it * 256 + wave * 64) * 16);
+            for (int it = 0; it < A_ITERS; ++it) {
+                if (LD == 1)
+                    bufld16(in_b, adst + (it * 256 + wave * 64) * 16, asrc[it] * 4, chunk * 64);
+                else
+                    glds16(ab + asrc[it], adst + (it * 256 + wave * 64) * 16);
+            }
         }
     };
 
@@ -145,14 +168,16 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
         for (int g = 0; g < 2; ++g) offB[ns][g] = jj * 64 + ((((2 * g + h) ^ ((jj >> 2) & 3))) << 4);
     }
 
-    f32x16 acc[WC::WM_SUB][WC::WN_SUB];
+    f32x16 acc[WM_SUB][WC::WN_SUB];
 #pragma unroll
-    for (int ms = 0; ms < WC::WM_SUB; ++ms)
+    for (int ms = 0; ms < WM_SUB; ++ms)
 #pragma unroll
         for (int ns = 0; ns < WC::WN_SUB; ++ns)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
+    long long t_start = 0, t_loop = 0;
+    if (ABL & 16) t_start = clock64();
     // ---- main loop: one barrier per (chunk, tap) step, next step's tiles in flight
     stage(0, 0, 0);
     int step = 0;
@@ -169,10 +194,10 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
             }
             const char* bbuf = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
             const int ky = tap / 3, kx = tap - ky * 3;
-            int offA[WC::WM_SUB];
+            int offA[WM_SUB];
 #pragma unroll
-            for (int ms = 0; ms < WC::WM_SUB; ++ms) {
-                const int msg = wave_m * WC::WM_SUB + ms;
+            for (int ms = 0; ms < WM_SUB; ++ms) {
+                const int msg = wave_m * WM_SUB + ms;
                 int pp;
                 if (TAPS == 1)
                     pp = (2 * msg + r_) * HWD + c_;
@@ -184,86 +209,105 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
             }
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                f32x4 a[WC::WM_SUB], bb[WC::WN_SUB];
+                f32x4 a[WM_SUB], bb[WC::WN_SUB];
 #pragma unroll
-                for (int ms = 0; ms < WC::WM_SUB; ++ms) a[ms] = *(const f32x4*)(abuf + (offA[ms] ^ (g << 5)));
+                for (int ms = 0; ms < WM_SUB; ++ms) a[ms] = *(const f32x4*)(abuf + (offA[ms] ^ (g << 5)));
 #pragma unroll
                 for (int ns = 0; ns < WC::WN_SUB; ++ns) bb[ns] = *(const f32x4*)(bbuf + offB[ns][g]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int ms = 0; ms < WC::WM_SUB; ++ms)
+                    for (int ms = 0; ms < WM_SUB; ++ms)
 #pragma unroll
                         for (int ns = 0; ns < WC::WN_SUB; ++ns)
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][s], bb[ns][s], acc[ms][ns], 0, 0, 0);
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[ns][s], a[ms][s], acc[ms][ns], 0, 0, 0);
             }
         }
     }
 
-    // ---- fused epilogue
+    if (ABL & 16) t_loop = clock64();
+    // ---- fused epilogue.  Weights are the MFMA "A" operand and pixels the "B" operand, so the
+    // accumulator of a lane holds ONE pixel (lane&31) x 16 output channels, (r&3)+8(r>>2)+4h:
+    // four runs of 4 consecutive channels -> 16-byte stores / residual loads / parameter loads.
     const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
     float* out_b = p.out + (size_t)b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
     const float* res_b = nullptr;
     if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
 #pragma unroll
     for (int ns = 0; ns < WC::WN_SUB; ++ns) {
-        const int co = n_tile * BN + (wave_n * WC::WN_SUB + ns) * 32 + l31;
-        const float bias = p.bias[co];
-        float m1 = 0, r1 = 1, lo1 = 0, hi1 = 0, m2 = 0, r2 = 1, lo2 = 0, hi2 = 0, smean = 0, sstd = 1;
-        if (EPI & E_NORM1) {
-            m1 = p.n1[co]; r1 = p.n1[p.Cout + co]; lo1 = p.n1[2 * p.Cout + co]; hi1 = p.n1[3 * p.Cout + co];
-        }
-        if (EPI & E_NORM2) {
-            m2 = p.n2[co]; r2 = p.n2[p.Cout + co]; lo2 = p.n2[2 * p.Cout + co]; hi2 = p.n2[3 * p.Cout + co];
-            smean = p.sty[co]; sstd = p.sty[p.Cout + co];
-        }
 #pragma unroll
-        for (int ms = 0; ms < WC::WM_SUB; ++ms) {
-            const int msg = wave_m * WC::WM_SUB + ms;
-            float v[16];
+        for (int cg = 0; cg < 4; ++cg) {
+            const int co = n_tile * BN + (wave_n * WC::WN_SUB + ns) * 32 + 8 * cg + 4 * h;
+            const f32x4 bias = *(const f32x4*)(p.bias + co);
+            f32x4 m1, r1, lo1, hi1, m2, r2, lo2, hi2, smean, sstd;
+            if (EPI & E_NORM1) {
+                m1 = *(const f32x4*)(p.n1 + co); r1 = *(const f32x4*)(p.n1 + p.Cout + co);
+                lo1 = *(const f32x4*)(p.n1 + 2 * p.Cout + co); hi1 = *(const f32x4*)(p.n1 + 3 * p.Cout + co);
+            }
+            if (EPI & E_NORM2) {
+                m2 = *(const f32x4*)(p.n2 + co); r2 = *(const f32x4*)(p.n2 + p.Cout + co);
+                lo2 = *(const f32x4*)(p.n2 + 2 * p.Cout + co); hi2 = *(const f32x4*)(p.n2 + 3 * p.Cout + co);
+                smean = *(const f32x4*)(p.sty + co); sstd = *(const f32x4*)(p.sty + p.Cout + co);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // C layout: row i = (r&3) + 8*(r>>2) + 4h  ->  sub-row i>>4, col i&15
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int y = y0 + 2 * msg + (i >> 4), x = x0 + (i & 15);
-                float t = acc[ms][ns][r] + bias;
-                if (EPI & E_RELU) t = fmaxf(t, 0.f);
-                if (EPI & E_LRELU) t = (t >= 0.f) ? t : t * 0.2f;
-                if (EPI & E_NORM1) {
-                    t = (t - m1) * r1;
-                    t = fminf(hi1, fmaxf(lo1, t));
+            for (int ms = 0; ms < WM_SUB; ++ms) {
+                const int msg = wave_m * WM_SUB + ms;
+                const int y = y0 + 2 * msg + r_, x = x0 + c_;
+                const bool valid = (y < p.H) && (x < p.W);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[ms][ns][4 * cg + e] + bias[e];
+                    if (EPI & E_RELU) t = fmaxf(t, 0.f);
+                    if (EPI & E_LRELU) t = (t >= 0.f) ? t : t * 0.2f;
+                    if (EPI & E_NORM1) {
+                        t = (t - m1[e]) * r1[e];
+                        t = fminf(hi1[e], fmaxf(lo1[e], t));
+                    }
+                    v[e] = t;
                 }
-                if (EPI & E_RES) {
-                    if (y < p.H && x < p.W) t += res_b[((y + 1) * (p.Wr + 2) + x + 1) * p.Cout + co];
-                }
-                if (EPI & E_RES_UPS) {
-                    if (y < p.H && x < p.W) t += res_b[(((y >> 1) + 1) * (p.Wr + 2) + (x >> 1) + 1) * p.Cout + co];
+                if (EPI & (E_RES | E_RES_UPS)) {
+                    if (valid) {
+                        const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
+                        v += *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + co);
+                    }
                 }
                 if (EPI & E_NORM2) {
-                    t = (t - m2) * r2;
-                    t = fminf(hi2, fmaxf(lo2, t));
-                    t = t * sstd + smean;
-                }
-                v[r] = t;
-            }
-            if (EPI & E_POOL) {
-                // 2x2 windows: rows = regs r, r+8 (sub-rows 0/1); cols = regs r, r+1
 #pragma unroll
-                for (int r = 0; r < 8; r += 2) {
-                    const float m = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + 8], v[r + 9]));
-                    const int cx = (r & 3) + 8 * (r >> 2) + 4 * h;   // even column inside the tile
-                    const int y2 = (y0 >> 1) + msg, x2 = (x0 + cx) >> 1;
-                    if (y2 < Ho && x2 < Wo) out_b[((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co] = m;
+                    for (int e = 0; e < 4; ++e) {
+                        float t = (v[e] - m2[e]) * r2[e];
+                        t = fminf(hi2[e], fmaxf(lo2[e], t));
+                        v[e] = t * sstd[e] + smean[e];
+                    }
                 }
-            } else {
+                if (EPI & E_POOL) {
+                    // 2x2 window = lanes {l, l^1 (next column), l^16 (next row), l^17}
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int y = y0 + 2 * msg + (i >> 4), x = x0 + (i & 15);
-                    if (ABL & 4) { if (v[r] == 123.456f) out_b[co] = v[r]; continue; }
-                    if (y < p.H && x < p.W) out_b[((y + 1) * (p.W + 2) + x + 1) * p.Cout + co] = v[r];
+                    for (int e = 0; e < 4; ++e) {
+                        float t = v[e];
+                        t = fmaxf(t, __shfl_xor(t, 1));
+                        t = fmaxf(t, __shfl_xor(t, 16));
+                        v[e] = t;
+                    }
+                    const int y2 = (y0 >> 1) + msg, x2 = (x0 + c_) >> 1;
+                    if (r_ == 0 && !(c_ & 1) && y2 < Ho && x2 < Wo) {
+                        if (ABL & 4) { if (v[0] == 123.456f) out_b[co] = v[0]; }
+                        else *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = v;
+                    }
+                } else if (valid) {
+                    if (ABL & 4) { if (v[0] == 123.456f) out_b[co] = v[0]; }
+                    else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = v;
                 }
             }
+        }
+    }
+    if (ABL & 16) {
+        __builtin_amdgcn_s_waitcnt(0);   // drain stores so t_end includes them
+        const long long t_end = clock64();
+        if (lane == 0) {
+            long long* dbg = (long long*)p.n1;   // microbench passes a debug buffer here
+            const int wg = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+            dbg[wg * 3 + 0] = t_start; dbg[wg * 3 + 1] = t_loop; dbg[wg * 3 + 2] = t_end;
         }
     }
 }
@@ -319,18 +363,17 @@ __global__ __launch_bounds__(256) void conv_ups2_k(const ConvP p) {
         const int hy = pp / HWD, hx = pp - hy * HWD;
         asrc[it] = ((ys + hy + 1) * (p.Wi + 2) + (xs + hx + 1)) * p.Cin + 4 * (qq ^ ((pp >> 2) & 3));
     }
-    const float* wsrc = p.wpk + (size_t)n_tile * nchunks * 16 * (BN * 16) + tid * 4;
+    const float* w_tile = p.wpk + (size_t)n_tile * nchunks * 16 * (BN * 16);
 
     auto stage = [&](int chunk, int tap, int step) {
         char* bdst = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
-        const float* wb = wsrc + (size_t)((chunk * 2 + py) * 4 + tap) * (2 * BN * 16);
 #pragma unroll
-        for (int it = 0; it < B_ITERS; ++it) glds16(wb + it * 1024, bdst + (it * 256 + wave * 64) * 16);
+        for (int it = 0; it < B_ITERS; ++it)
+            bufld16(w_tile, bdst + (it * 256 + wave * 64) * 16, tid * 16 + it * 4096, ((chunk * 2 + py) * 4 + tap) * (2 * BN * 64));
         if (tap == 0) {
             char* adst = smem + (chunk & 1) * A_BYTES;
-            const float* ab = in_b + chunk * 16;
 #pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) glds16(ab + asrc[it], adst + (it * 256 + wave * 64) * 16);
+            for (int it = 0; it < A_ITERS; ++it) bufld16(in_b, adst + (it * 256 + wave * 64) * 16, asrc[it] * 4, chunk * 64);
         }
     };
 
@@ -383,35 +426,40 @@ __global__ __launch_bounds__(256) void conv_ups2_k(const ConvP p) {
                     for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
                         for (int ns = 0; ns < WC::WN_SUB; ++ns)
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][s], bb[ns][s], acc[ms][ns], 0, 0, 0);
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[ns][s], a[ms][s], acc[ms][ns], 0, 0, 0);
             }
         }
     }
 
+    // lane = low-res position (r_, c_) of its (px, row-half) block; registers = 16 output channels
     float* out_b = p.out + (size_t)b * (size_t)(p.H + 2) * (p.W + 2) * p.Cout;
 #pragma unroll
     for (int ns = 0; ns < WC::WN_SUB; ++ns) {
-        const int co = n_tile * BN + (wave_n * WC::WN_SUB + ns) * 32 + l31;
-        const float bias = p.bias[co];
-        float m1 = 0, r1 = 1, lo1 = 0, hi1 = 0;
-        if (EPI & E_NORM1) {
-            m1 = p.n1[co]; r1 = p.n1[p.Cout + co]; lo1 = p.n1[2 * p.Cout + co]; hi1 = p.n1[3 * p.Cout + co];
-        }
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
+        for (int cg = 0; cg < 4; ++cg) {
+            const int co = n_tile * BN + (wave_n * WC::WN_SUB + ns) * 32 + 8 * cg + 4 * h;
+            const f32x4 bias = *(const f32x4*)(p.bias + co);
+            f32x4 m1, r1, lo1, hi1;
+            if (EPI & E_NORM1) {
+                m1 = *(const f32x4*)(p.n1 + co); r1 = *(const f32x4*)(p.n1 + p.Cout + co);
+                lo1 = *(const f32x4*)(p.n1 + 2 * p.Cout + co); hi1 = *(const f32x4*)(p.n1 + 3 * p.Cout + co);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // C row i = (r&3) + 8*(r>>2) + 4h = rr*8 + cc with rr = r>>2, cc = (r&3) + 4h
-                const int rr = r >> 2, cc = (r & 3) + 4 * h;
-                const int y = y0 + 2 * (ms * 4 + rr) + py, x = x0 + 2 * cc + px;
-                float t = acc[ms][ns][r] + bias;
-                if (EPI & E_RELU) t = fmaxf(t, 0.f);
-                if (EPI & E_LRELU) t = (t >= 0.f) ? t : t * 0.2f;
-                if (EPI & E_NORM1) {
-                    t = (t - m1) * r1;
-                    t = fminf(hi1, fmaxf(lo1, t));
+            for (int ms = 0; ms < 2; ++ms) {
+                const int y = y0 + 2 * (ms * 4 + r_) + py, x = x0 + 2 * c_ + px;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[ms][ns][4 * cg + e] + bias[e];
+                    if (EPI & E_RELU) t = fmaxf(t, 0.f);
+                    if (EPI & E_LRELU) t = (t >= 0.f) ? t : t * 0.2f;
+                    if (EPI & E_NORM1) {
+                        t = (t - m1[e]) * r1[e];
+                        t = fminf(hi1[e], fmaxf(lo1[e], t));
+                    }
+                    v[e] = t;
                 }
-                if (y < p.H && x < p.W) out_b[((y + 1) * (p.W + 2) + x + 1) * p.Cout + co] = t;
+                if (y < p.H && x < p.W) *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = v;
             }
         }
     }

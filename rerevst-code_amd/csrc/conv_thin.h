@@ -11,7 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "conv_mfma.h"   // bufld16
 
 struct FirstP {
     const uint8_t* img;   // [B][H][W][3] BGR
@@ -118,10 +118,8 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
         for (int e = tid; e < 18 * 18 * 4; e += 256) {
             const int pp = e >> 2, qq = e & 3;
             const int hy = pp / 18, hx = pp - hy * 18;
-            const float* src = in_b + ((size_t)(y0 + hy) * (p.W + 2) + x0 + hx) * 64 + chunk * 16 + 4 * (qq ^ ((pp >> 2) & 3));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)((char*)&s_in[buf][0] + (e - (tid & 63)) * 16),
-                                             16, 0, 0);
+            const int off = (((y0 + hy) * (p.W + 2) + x0 + hx) * 64 + 4 * (qq ^ ((pp >> 2) & 3))) * 4;
+            bufld16(in_b, (char*)&s_in[buf][0] + (e - (tid & 63)) * 16, off, chunk * 64);
         }
     };
     float acc[3] = {0.f, 0.f, 0.f};

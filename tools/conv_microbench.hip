@@ -8,15 +8,16 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int BN, int TAPS, int EPI, int ABL>
-float run(const ConvP& p, int iters) {
+template <int BN, int TAPS, int EPI, int ABL, int MSUB = 0, int LD = 0>
+float run(ConvP p, int iters) {
+    if (MSUB) p.tiles_y = (p.H + MSUB * 4 - 1) / (MSUB * 4);
     dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / BN);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, false, EPI, ABL>), grid, dim3(256), 0, 0, p);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, false, EPI, ABL, MSUB, LD>), grid, dim3(256), 0, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, false, EPI, ABL>), grid, dim3(256), 0, 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, false, EPI, ABL, MSUB, LD>), grid, dim3(256), 0, 0, p);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -44,9 +45,27 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     const int it = 10;
     float t0 = run<BN, 9, E_RELU, 0>(p, it), t1 = run<BN, 9, E_RELU, 1>(p, it), t2 = run<BN, 9, E_RELU, 2>(p, it),
           t3 = run<BN, 9, E_RELU, 3>(p, it), t4 = run<BN, 9, E_RELU, 4>(p, it), t7 = run<BN, 9, E_RELU, 7>(p, it);
+    float u1 = run<BN, 9, E_RELU, 0, 0, 1>(p, it), u2 = run<BN, 9, E_RELU, 0, 4, 0>(p, it), u3 = run<BN, 9, E_RELU, 0, 4, 1>(p, it),
+          u4 = run<BN, 9, E_RELU, 1, 4, 0>(p, it), u5 = run<BN, 9, E_RELU, 4, 4, 0>(p, it);
+    printf("%-28s bufferlds %.1f TF | BM256 %.1f | BM256+bufferlds %.1f | BM256 noload %.1f | BM256 nostore %.1f\n", name, fl / u1 / 1e9, fl / u2 / 1e9,
+           fl / u3 / 1e9, fl / u4 / 1e9, fl / u5 / 1e9);
     printf("%-28s base %.3f ms %.1f TF | noload %.1f | nobarrier %.1f | noload+nobar %.1f | nostore %.1f | none %.1f TF  (WGs=%d)\n", name, t0,
            fl / t0 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9, fl / t3 / 1e9, fl / t4 / 1e9, fl / t7 / 1e9,
            p.tiles_x * p.tiles_y * B * (Cout / BN));
+    {   // per-wave timeline (s_memtime): loop time vs epilogue time, and the spread of WG start times
+        const int nw = p.tiles_x * p.tiles_y * B * (Cout / BN) * 4;
+        long long* dbg; CK(hipMalloc(&dbg, (size_t)nw * 3 * 8));
+        ConvP q = p; q.n1 = (const float*)dbg;
+        dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / BN);
+        hipLaunchKernelGGL((conv_mfma_k<BN, 9, false, E_RELU, 16>), grid, dim3(256), 0, 0, q);
+        CK(hipDeviceSynchronize());
+        std::vector<long long> h((size_t)nw * 3);
+        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double loop = 0, epi = 0; long long tmin = h[0], tmax = h[2];
+        for (int i = 0; i < nw; ++i) { loop += h[i*3+1]-h[i*3]; epi += h[i*3+2]-h[i*3+1]; if (h[i*3]<tmin) tmin=h[i*3]; if (h[i*3+2]>tmax) tmax=h[i*3+2]; }
+        printf("     timeline: avg loop %.0f clk, avg epilogue %.0f clk (%.1f%%), kernel span %.0f clk (100MHz ticks?)\n", loop/nw, epi/nw, 100.0*epi/(loop+epi), (double)(tmax-tmin));
+        CK(hipFree(dbg));
+    }
     CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));
 }
 
