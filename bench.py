@@ -29,13 +29,14 @@ PEAK_HBM_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
     ap.add_argument("--size", type=int, default=512, help="frame side (256/512/1024)")
     ap.add_argument("--frames", type=int, default=300, help="frames of the synthetic video")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--profile-steps", type=int, default=4)
+    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight per GPU (1 or 2 HIP streams)")
     args = ap.parse_args()
 
     import torch
@@ -64,6 +65,7 @@ def main():
 
     weights = pkg.synthetic_weights(0)
     model = pkg.Stylization(weights, cuda=True, device=local)
+    model.set_pipeline(args.pipeline)
 
     # ---- synthetic video: this rank's shard, padded, resident in HBM --------------------
     B = args.batch
@@ -72,7 +74,7 @@ def main():
     my_ids = [(first + i) % NF for i in range(n_batches * B)]
     host = np.stack([video.reflect_pad(pkg.synth_frame(i, S, S, kind="noise"), P, P) for i in my_ids])
     d_frames = torch.from_numpy(host).to(dev).view(n_batches, B, P, P, 3)
-    d_out = torch.empty((2, B, P, P, 3), dtype=torch.float32, device=dev)
+    d_out = torch.empty((4, B, P, P, 3), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     # ---- once-per-video preparation on rank 0, state broadcast over RCCL ------------------
@@ -92,7 +94,7 @@ def main():
             model.set_state(blob.cpu().numpy())
 
     def step(i):
-        model.transfer_batch_device(d_frames[i % n_batches].data_ptr(), B, P, P, d_out[i & 1].data_ptr())
+        model.transfer_batch_device(d_frames[i % n_batches].data_ptr(), B, P, P, d_out[i & 3].data_ptr())
 
     for i in range(args.warmup):
         step(i)
@@ -167,7 +169,7 @@ def main():
                "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%d-frame synthetic %dx%d video (padded %dx%d), 1 style, frames sharded per GPU"
-                                      % (NF, S, S, P, P), "frames_per_step_per_gpu": B, "sampled_frames": len(video.sample_indices(NF)),
+                                      % (NF, S, S, P, P), "frames_per_step_per_gpu": B, "batches_in_flight": args.pipeline, "sampled_frames": len(video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
                "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu, "prep_seconds_rank0": round(prep_s, 3), "kernels": kern}
         print(json.dumps(out), flush=True)

@@ -36,6 +36,7 @@ enum {
  * (test/style_network_global.py:37-40,148,171,330).  Layout documented in DESIGN.md. */
 #define RRV_STATE_FLOATS 17536
 #define RRV_MAX_STYLES 8
+#define RRV_MAX_SLOTS 4
 
 /* Stylization.__init__ (test/framework.py:57-78): picks the device and builds the model.
  * `device` is the HIP device ordinal. */
@@ -103,6 +104,12 @@ int rrv_transfer_blend(rrv_handle h, const uint8_t* frame_bgr, int H, int W, con
 int rrv_get_preclamp(rrv_handle h, float* out, int H, int W);
 
 int rrv_sync(rrv_handle h);
+
+/* Consecutive rrv_transfer[_batch]_device calls alternate over n_slots (1..RRV_MAX_SLOTS, default 2) internal
+ * (HIP stream, workspace) pairs, so n_slots independent batches are in flight and one batch's kernel
+ * tails overlap the other's kernels.  Callers must give consecutive calls distinct output buffers
+ * and call rrv_sync() before reading them.  Host-buffer entries and blend transfers are serialised. */
+int rrv_set_pipeline(rrv_handle h, int n_slots);
 
 /* Per-launch timing with HIP events recorded on the handle's own stream.
  * rrv_profile_begin() clears the log and starts bracketing every kernel launch with

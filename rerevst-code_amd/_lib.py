@@ -35,6 +35,7 @@ SYMBOLS = {
     "rrv_transfer_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "rrv_get_preclamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_sync": (C.c_int, [C.c_void_p]),
+    "rrv_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_profile_begin": (C.c_int, [C.c_void_p]),
     "rrv_profile_end": (C.c_int, [C.c_void_p]),
     "rrv_profile_count": (C.c_int, [C.c_void_p]),

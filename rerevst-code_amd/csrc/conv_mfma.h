@@ -302,12 +302,13 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
         }
     }
     if (ABL & 16) {
+        const long long t_issued = clock64();
         __builtin_amdgcn_s_waitcnt(0);   // drain stores so t_end includes them
         const long long t_end = clock64();
         if (lane == 0) {
             long long* dbg = (long long*)p.n1;   // microbench passes a debug buffer here
             const int wg = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
-            dbg[wg * 3 + 0] = t_start; dbg[wg * 3 + 1] = t_loop; dbg[wg * 3 + 2] = t_end;
+            dbg[wg * 4 + 0] = t_start; dbg[wg * 4 + 1] = t_loop; dbg[wg * 4 + 2] = t_issued; dbg[wg * 4 + 3] = t_end;
         }
     }
 }

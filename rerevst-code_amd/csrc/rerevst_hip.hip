@@ -74,7 +74,9 @@ struct StyleState {
 
 struct rrv_ctx {
     int dev = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;              // stream the launch helpers use (= streams[slot in use])
+    hipStream_t streams[RRV_MAX_SLOTS] = {nullptr};
+    int n_slots = 2, next_slot = 0, last_slot = 0;   // transfer calls alternate over n_slots (stream, workspace) pairs
     std::string err;
     std::map<std::string, std::vector<float>> hostw;
     std::map<std::string, std::vector<int64_t>> hostshape;
@@ -90,8 +92,8 @@ struct rrv_ctx {
     StyleState styles[RRV_MAX_STYLES];
     float* active = nullptr;                   // state the per-frame path reads (blob layout)
     int active_src = -1;                       // style id whose state is folded (-2: blend)
-    EncPlan enc_frame, enc_add, enc_style;
-    DecPlan dec;
+    EncPlan enc_frame[RRV_MAX_SLOTS], enc_add, enc_style;
+    DecPlan dec[RRV_MAX_SLOTS];
     std::vector<float*> patches;               // relu4_1 features of added frames (ring layout images)
     int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
@@ -115,6 +117,12 @@ namespace {
 #define RCHK(expr) do { int _r = (expr); if (_r != RRV_OK) return _r; } while (0)
 
 int fail(rrv_handle h, int code, const std::string& msg) { h->err = msg; return code; }
+
+int sync_all(rrv_handle h) {
+    for (int i = 0; i < RRV_MAX_SLOTS; ++i)
+        if (h->streams[i]) HIPCHK(hipStreamSynchronize(h->streams[i]));
+    return RRV_OK;
+}
 
 int dalloc(rrv_handle h, float** p, size_t floats, bool zero = true) {
     HIPCHK(hipMalloc((void**)p, floats * sizeof(float)));
@@ -328,9 +336,11 @@ int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
 
 int activate_state(rrv_handle h, int style_id) {
     if (h->active_src == style_id) return RRV_OK;
+    RCHK(sync_all(h));
     StyleState& s = h->styles[style_id];
     HIPCHK(hipMemcpyAsync(h->active, s.blob, RRV_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->active_src = style_id;
     return RRV_OK;
 }
@@ -426,10 +436,17 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
     if (h->active_src == -1) return fail(h, RRV_E_STATE, "state not computed: call compute() (or set_state) before transfer()");
     if (B < 1 || B > 64) return fail(h, RRV_E_ARG, "transfer: batch must be in 1..64");
-    RCHK(enc_plan(h, h->enc_frame, B, H, W));
-    RCHK(dec_plan(h, h->dec, B, H, W));
-    DecPlan& d = h->dec;
-    EncPlan& e = h->enc_frame;
+    // consecutive calls alternate over two (stream, workspace) pairs so that the tail / store burst of
+    // one batch's kernels overlaps the next batch's kernels (frames are independent)
+    const int slot = (h->n_slots > 1 && !h->profiling) ? h->next_slot : 0;
+    h->next_slot = (slot + 1) % h->n_slots;
+    h->last_slot = slot;
+    struct StreamScope { rrv_handle h; ~StreamScope() { h->stream = h->streams[0]; } } scope{h};
+    h->stream = h->streams[slot];
+    RCHK(enc_plan(h, h->enc_frame[slot], B, H, W));
+    RCHK(dec_plan(h, h->dec[slot], B, H, W));
+    DecPlan& d = h->dec[slot];
+    EncPlan& e = h->enc_frame[slot];
     const float* st = h->active;
     RCHK(run_encoder(h, e, d_in, 0, st + SL.norm[N_DEC0]));
     const Tens* cur = &e.c41;
@@ -552,10 +569,13 @@ int rrv_create(int device, rrv_handle* out) {
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return RRV_E_HIP;
     rrv_ctx* h = new rrv_ctx();
     h->dev = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    bool ok = hipSetDevice(device) == hipSuccess;
+    for (int i = 0; ok && i < RRV_MAX_SLOTS; ++i) ok = hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking) == hipSuccess;
+    if (!ok) {
         delete h;
         return RRV_E_HIP;
     }
+    h->stream = h->streams[0];
     *out = h;
     return RRV_OK;
 }
@@ -571,15 +591,15 @@ int rrv_destroy(rrv_handle h) {
         if (kv.second.pk_ups) (void)hipFree(kv.second.pk_ups);
     }
     for (float* p : h->patches) (void)hipFree(p);
-    for (EncPlan* e : {&h->enc_frame, &h->enc_add, &h->enc_style})
+    for (EncPlan* e : {&h->enc_frame[0], &h->enc_frame[1], &h->enc_frame[2], &h->enc_frame[3], &h->enc_add, &h->enc_style})
         for (Tens* t : {&e->c11, &e->p1, &e->c21, &e->p2, &e->c31, &e->c32, &e->c33, &e->p3, &e->c41}) tfree(t);
-    DecPlan& d = h->dec;
-    for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2}) tfree(t);
+    for (DecPlan& d : h->dec)
+        for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2}) tfree(t);
     for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->d_outf) (void)hipFree(h->d_outf);
     for (ProfEntry& e : h->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
-    (void)hipStreamDestroy(h->stream);
+    for (int i = 0; i < RRV_MAX_SLOTS; ++i) (void)hipStreamDestroy(h->streams[i]);
     delete h;
     return RRV_OK;
 }
@@ -672,6 +692,7 @@ int rrv_prepare_style(rrv_handle h, const uint8_t* style, int Hs, int Ws, int si
     if (!h || !style || Hs < 8 || Ws < 8 || sid < 0 || sid >= RRV_MAX_STYLES) return RRV_E_ARG;
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
     HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
     StyleState& S = h->styles[sid];
     if (!S.blob) RCHK(dalloc(h, &S.blob, RRV_STATE_FLOATS));
     RCHK(ensure_u8(h, (size_t)Hs * Ws * 3));
@@ -693,7 +714,7 @@ int rrv_prepare_style(rrv_handle h, const uint8_t* style, int Hs, int Ws, int si
 int rrv_clean(rrv_handle h) {
     if (!h) return RRV_E_ARG;
     (void)hipSetDevice(h->dev);
-    (void)hipStreamSynchronize(h->stream);
+    (void)sync_all(h);
     for (float* p : h->patches) (void)hipFree(p);
     h->patches.clear();
     h->patch_h = h->patch_w = h->add_H = h->add_W = 0;
@@ -706,6 +727,7 @@ int rrv_add(rrv_handle h, const uint8_t* frame, int H, int W) {
     if (!h || !frame || H < 8 || W < 8) return RRV_E_ARG;
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
     HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
     if (!h->patches.empty() && (H != h->add_H || W != h->add_W))
         return fail(h, RRV_E_ARG, "add: all sampled frames must have the same size");
     RCHK(ensure_u8(h, (size_t)H * W * 3));
@@ -725,6 +747,7 @@ int rrv_add(rrv_handle h, const uint8_t* frame, int H, int W) {
 int rrv_compute(rrv_handle h) {
     if (!h) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
     if (h->patches.empty()) return fail(h, RRV_E_STATE, "compute: no frames added");
     int nprep = 0;
     for (StyleState& s : h->styles) nprep += s.prepared ? 1 : 0;
@@ -750,7 +773,7 @@ int rrv_get_state(rrv_handle h, float* out, int n, int sid) {
     StyleState& S = h->styles[sid];
     if (!S.blob || !S.computed) return fail(h, RRV_E_STATE, "get_state: state not computed for this style");
     HIPCHK(hipSetDevice(h->dev));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    RCHK(sync_all(h));
     HIPCHK(hipMemcpy(out, S.blob, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return RRV_OK;
 }
@@ -761,7 +784,7 @@ int rrv_set_state(rrv_handle h, const float* in, int n, int sid) {
     HIPCHK(hipSetDevice(h->dev));
     StyleState& S = h->styles[sid];
     if (!S.blob) RCHK(dalloc(h, &S.blob, RRV_STATE_FLOATS));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    RCHK(sync_all(h));
     HIPCHK(hipMemcpy(S.blob, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     S.computed = true;
     if (h->active_src == sid || h->active_src == -1) { h->active_src = -1; RCHK(activate_state(h, sid)); }
@@ -786,6 +809,8 @@ int rrv_transfer_device(rrv_handle h, const void* d_in, int H, int W, void* d_ou
 int rrv_transfer_blend_device(rrv_handle h, const void* d_in, int H, int W, const float* wts, int ns, void* d_out) {
     if (!h || !d_in || !d_out || !wts || ns < 1 || ns > RRV_MAX_STYLES) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    h->next_slot = 0;
     BlendP bp{};
     bp.n = ns; bp.out = h->active; bp.count = RRV_STATE_FLOATS;
     for (int s = 0; s < ns; ++s) {
@@ -796,7 +821,9 @@ int rrv_transfer_blend_device(rrv_handle h, const void* d_in, int H, int W, cons
     HIPCHK(hipGetLastError());
     for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
     h->active_src = -2;
-    return transfer_device(h, (const uint8_t*)d_in, 1, H, W, (float*)d_out);
+    const int rc = transfer_device(h, (const uint8_t*)d_in, 1, H, W, (float*)d_out);
+    h->next_slot = 0;
+    return rc;
 }
 
 // host-buffer wrappers: H2D, same device path, D2H
@@ -811,11 +838,14 @@ static int host_roundtrip(rrv_handle h, const uint8_t* frames, int B, int H, int
         HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
         h->d_outf_cap = n;
     }
-    HIPCHK(hipMemcpyAsync(h->d_u8, frames, n, hipMemcpyHostToDevice, h->stream));
+    RCHK(sync_all(h));
+    h->next_slot = 0;                                   // the shared staging buffers serialise this path
+    HIPCHK(hipMemcpyAsync(h->d_u8, frames, n, hipMemcpyHostToDevice, h->streams[0]));
     if (wts) RCHK(rrv_transfer_blend_device(h, h->d_u8, H, W, wts, ns, h->d_outf));
     else RCHK(rrv_transfer_batch_device(h, h->d_u8, B, H, W, h->d_outf));
-    HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->next_slot = 0;
+    HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
+    HIPCHK(hipStreamSynchronize(h->streams[0]));
     return RRV_OK;
 }
 
@@ -834,17 +864,26 @@ int rrv_transfer_blend(rrv_handle h, const uint8_t* frame, int H, int W, const f
 
 int rrv_get_preclamp(rrv_handle h, float* out, int H, int W) {
     if (!h || !out) return RRV_E_ARG;
-    if (!h->dec.pre || h->dec.H != H || h->dec.W != W || h->dec.B < 1) return fail(h, RRV_E_STATE, "get_preclamp: no transfer of that size yet");
+    const DecPlan& d = h->dec[h->last_slot];
+    if (!d.pre || d.H != H || d.W != W || d.B < 1) return fail(h, RRV_E_STATE, "get_preclamp: no transfer of that size yet");
     HIPCHK(hipSetDevice(h->dev));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, h->dec.pre, (size_t)H * W * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    RCHK(sync_all(h));
+    HIPCHK(hipMemcpy(out, d.pre, (size_t)H * W * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return RRV_OK;
 }
 
 int rrv_sync(rrv_handle h) {
     if (!h) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    return sync_all(h);
+}
+
+int rrv_set_pipeline(rrv_handle h, int n_slots) {
+    if (!h || n_slots < 1 || n_slots > RRV_MAX_SLOTS) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    h->n_slots = n_slots;
+    h->next_slot = 0;
     return RRV_OK;
 }
 
@@ -852,6 +891,7 @@ int rrv_profile_begin(rrv_handle h) {
     if (!h) return RRV_E_ARG;
     for (ProfEntry& e : h->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     h->prof.clear();
+    (void)sync_all(h);          // profiled launches run un-pipelined on slot 0 so event intervals do not overlap
     h->profiling = true;
     return RRV_OK;
 }
@@ -860,7 +900,7 @@ int rrv_profile_end(rrv_handle h) {
     if (!h) return RRV_E_ARG;
     h->profiling = false;
     HIPCHK(hipSetDevice(h->dev));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    RCHK(sync_all(h));
     for (ProfEntry& e : h->prof) HIPCHK(hipEventElapsedTime(&e.ms, e.e0, e.e1));
     return RRV_OK;
 }

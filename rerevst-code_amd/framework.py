@@ -129,6 +129,11 @@ class Stylization():
     def sync(self):
         self._chk(self._lib.rrv_sync(self._h))
 
+    def set_pipeline(self, n_slots):
+        """1: every device-entry call runs on one stream; 2 (default): consecutive calls alternate over two
+        (stream, workspace) pairs so two independent batches are in flight."""
+        self._chk(self._lib.rrv_set_pipeline(self._h, int(n_slots)))
+
     # ===== shared state (RCCL broadcast payload / golden comparison) =====
     def get_state(self, style_id=0):
         out = np.empty(_lib.STATE_FLOATS, dtype=np.float32)

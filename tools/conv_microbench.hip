@@ -8,7 +8,7 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int BN, int TAPS, int EPI, int ABL, int MSUB = 0, int LD = 0>
+template <int BN, int TAPS, int EPI, int ABL, int MSUB = 0, int LD = 1>
 float run(ConvP p, int iters) {
     if (MSUB) p.tiles_y = (p.H + MSUB * 4 - 1) / (MSUB * 4);
     dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / BN);
@@ -54,16 +54,16 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
            p.tiles_x * p.tiles_y * B * (Cout / BN));
     {   // per-wave timeline (s_memtime): loop time vs epilogue time, and the spread of WG start times
         const int nw = p.tiles_x * p.tiles_y * B * (Cout / BN) * 4;
-        long long* dbg; CK(hipMalloc(&dbg, (size_t)nw * 3 * 8));
+        long long* dbg; CK(hipMalloc(&dbg, (size_t)nw * 4 * 8));
         ConvP q = p; q.n1 = (const float*)dbg;
         dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / BN);
         hipLaunchKernelGGL((conv_mfma_k<BN, 9, false, E_RELU, 16>), grid, dim3(256), 0, 0, q);
         CK(hipDeviceSynchronize());
-        std::vector<long long> h((size_t)nw * 3);
+        std::vector<long long> h((size_t)nw * 4);
         CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double loop = 0, epi = 0; long long tmin = h[0], tmax = h[2];
-        for (int i = 0; i < nw; ++i) { loop += h[i*3+1]-h[i*3]; epi += h[i*3+2]-h[i*3+1]; if (h[i*3]<tmin) tmin=h[i*3]; if (h[i*3+2]>tmax) tmax=h[i*3+2]; }
-        printf("     timeline: avg loop %.0f clk, avg epilogue %.0f clk (%.1f%%), kernel span %.0f clk (100MHz ticks?)\n", loop/nw, epi/nw, 100.0*epi/(loop+epi), (double)(tmax-tmin));
+        double loop = 0, epi = 0, drain = 0;
+        for (int i = 0; i < nw; ++i) { loop += h[i*4+1]-h[i*4]; epi += h[i*4+2]-h[i*4+1]; drain += h[i*4+3]-h[i*4+2]; }
+        printf("     timeline: avg loop %.0f clk, epilogue issue %.0f clk, store drain %.0f clk\n", loop/nw, epi/nw, drain/nw);
         CK(hipFree(dbg));
     }
     CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(w)); CK(hipFree(bias));
