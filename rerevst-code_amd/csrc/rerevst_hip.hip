@@ -6,12 +6,14 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "../../include/rerevst_hip.h"
 #include "conv_mfma.h"
+#include "conv_wino.h"
 #include "conv_thin.h"
 #include "prep_kernels.h"
 
@@ -41,6 +43,7 @@ struct Tens {
 struct ConvW {           // one convolution's device weights
     float* raw = nullptr;    // OIHW as in the checkpoint
     float* pk = nullptr;     // kernel-native packed
+    float* pk_wino = nullptr; // Winograd F(2x2,3x3) transformed pack for conv_wino_k
     float* pk_ups = nullptr; // parity-folded pack for conv_ups2_k (convs that follow a nearest-x2 upsample)
     float* bias = nullptr;   // [Cout] (zeros for bias-free convs)
     int Cout = 0, Cin = 0, taps = 0, BN = 0;
@@ -98,6 +101,7 @@ struct rrv_ctx {
     int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
     float* d_outf = nullptr; size_t d_outf_cap = 0;
+    bool use_wino = true;                      // Winograd F(2x2,3x3) for the 3x3 layers that have a transformed pack
     bool profiling = false;
     std::vector<ProfEntry> prof;
 };
@@ -193,10 +197,30 @@ void ups2_launch(const ConvP& p, dim3 grid, hipStream_t s) {
 #define UK(BN, EPI) {BN, 9, 1, EPI, &ups2_launch<BN, EPI>, "conv_ups2<" #BN "," #EPI ">"}
 const ConvKey UPS_TABLE[] = {UK(128, E_LRELU | E_NORM1), UK(64, E_LRELU | E_NORM1), UK(128, E_LRELU), UK(64, E_LRELU)};
 
+template <int EPI>
+void wino_launch(const ConvP& p, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;     // >64 KB of dynamic LDS needs the opt-in attribute once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wino_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_SMEM_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wino_k<EPI>), grid, dim3(256), WINO_SMEM_BYTES, s, p);
+}
+#define WK(EPI) {32, 9, 0, EPI, &wino_launch<EPI>, "conv_wino<" #EPI ">"}
+const ConvKey WINO_TABLE[] = {
+    WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
+};
+
 int conv(rrv_handle h, const ConvCall& c) {
     const ConvW& w = *c.w;
     const ConvKey* k = nullptr;
-    if (c.ups) {
+    bool wino = false;
+    if (!c.ups && w.pk_wino && h->use_wino) {
+        for (const ConvKey& e : WINO_TABLE)
+            if (e.EPI == c.epi) { k = &e; wino = true; break; }
+    }
+    if (k) {
+    } else if (c.ups) {
         for (const ConvKey& e : UPS_TABLE)
             if (e.BN == w.BN && e.EPI == c.epi) { k = &e; break; }
     } else {
@@ -212,7 +236,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W; p.Cin = w.Cin;
     p.out = c.out->p; p.H = c.H; p.W = c.W; p.Cout = w.Cout; p.B = c.B;
     p.in_bstride0 = 1;
-    p.wpk = c.ups ? w.pk_ups : w.pk; p.bias = w.bias;
+    p.wpk = wino ? w.pk_wino : (c.ups ? w.pk_ups : w.pk); p.bias = w.bias;
     if (!p.wpk) return fail(h, RRV_E_ARG, "conv: weights not packed for this kernel"); p.n1 = c.n1; p.n2 = c.n2; p.sty = c.sty;
     if (c.res) { p.res = c.res->p; p.Hr = c.res->H; p.Wr = c.res->W; }
     p.tiles_x = (c.W + 15) / 16; p.tiles_y = (c.H + 7) / 8;
@@ -221,10 +245,11 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (c.in->H != eh || c.in->W != ew) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
     if (c.out->H != oh || c.out->W != ow) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
-    if (c.ups) { p.tiles_y = (c.H + 15) / 16; }
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B * (c.ups ? 2 : 1)), (unsigned)(w.Cout / w.BN));
+    if (c.ups || wino) { p.tiles_y = (c.H + 15) / 16; }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B * (c.ups ? 2 : 1)), (unsigned)(w.Cout / (wino ? 32 : w.BN)));
     const double px = (double)c.B * c.H * c.W;
-    const double flops = 2.0 * px * w.Cout * w.Cin * (c.ups ? 4 : w.taps);   // executed MACs (ups2 folds 9 taps into 4)
+    // executed multiply-adds: ups2 folds 9 taps into 4; Winograd F(2x2,3x3) needs 16 per 2x2 outputs (= 4 per pixel)
+    const double flops = 2.0 * px * w.Cout * w.Cin * ((c.ups || wino) ? 4 : w.taps);
     const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * w.Cin + (double)c.B * oh * ow * w.Cout +
                                 (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps);
     hipStream_t s = h->stream;
@@ -253,6 +278,14 @@ int pack(rrv_handle h, ConvW& w) {
 
 int bn_for(int cout) { return cout >= 128 ? 128 : (cout >= 64 ? 64 : 32); }
 
+int pack_wino(rrv_handle h, ConvW& w) {
+    const size_t total = (size_t)w.Cout * w.Cin * 16;
+    if (!w.pk_wino) RCHK(dalloc(h, &w.pk_wino, total, false));
+    hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_wino, w.Cout, w.Cin);
+    HIPCHK(hipGetLastError());
+    return RRV_OK;
+}
+
 int pack_ups(rrv_handle h, ConvW& w) {
     const size_t total = (size_t)w.Cout * w.Cin * 16;
     if (!w.pk_ups) RCHK(dalloc(h, &w.pk_ups, total, false));
@@ -268,6 +301,7 @@ int make_conv(rrv_handle h, const std::string& prefix, int cout, int cin, int ta
     if (has_bias) RCHK(upload(h, prefix + ".bias", &w.bias, (size_t)cout));
     else w.bias = h->zero_bias;
     if (do_pack) RCHK(pack(h, w));
+    if (do_pack && taps == 9 && cin >= 64 && cout >= 64) RCHK(pack_wino(h, w));
     h->conv[prefix] = w;
     return RRV_OK;
 }
@@ -576,6 +610,7 @@ int rrv_create(int device, rrv_handle* out) {
         return RRV_E_HIP;
     }
     h->stream = h->streams[0];
+    if (const char* e = getenv("RRV_WINO")) h->use_wino = (e[0] != '0');
     *out = h;
     return RRV_OK;
 }
@@ -589,6 +624,7 @@ int rrv_destroy(rrv_handle h) {
         if (kv.second.raw) (void)hipFree(kv.second.raw);
         if (kv.second.pk) (void)hipFree(kv.second.pk);
         if (kv.second.pk_ups) (void)hipFree(kv.second.pk_ups);
+        if (kv.second.pk_wino) (void)hipFree(kv.second.pk_wino);
     }
     for (float* p : h->patches) (void)hipFree(p);
     for (EncPlan* e : {&h->enc_frame[0], &h->enc_frame[1], &h->enc_frame[2], &h->enc_frame[3], &h->enc_add, &h->enc_style})

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "../rerevst-code_amd/csrc/conv_mfma.h"
+#include "../rerevst-code_amd/csrc/conv_wino.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -25,13 +26,31 @@ float run(ConvP p, int iters) {
     return ms / iters;
 }
 
+template <int ABL>
+float run_wino(ConvP p, int iters) {
+    p.tiles_y = (p.H + 15) / 16;
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / 32);
+    CK(hipFuncSetAttribute((const void*)conv_wino_k<E_RELU, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_SMEM_BYTES));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL>), grid, dim3(256), WINO_SMEM_BYTES, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL>), grid, dim3(256), WINO_SMEM_BYTES, 0, p);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
 template <int BN>
 void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     const size_t in_f = (size_t)B * (H + 2) * (W + 2) * Cin + (size_t)20 * (W + 22) * Cin;
     const size_t out_f = (size_t)B * (H + 2) * (W + 2) * Cout + (size_t)20 * (W + 22) * Cout;
     float *in, *out, *w, *bias;
     CK(hipMalloc(&in, in_f * 4)); CK(hipMalloc(&out, out_f * 4));
-    CK(hipMalloc(&w, (size_t)Cout * Cin * 9 * 4)); CK(hipMalloc(&bias, Cout * 4));
+    CK(hipMalloc(&w, (size_t)Cout * Cin * 16 * 4)); CK(hipMemset(w, 0, (size_t)Cout * Cin * 16 * 4)); CK(hipMalloc(&bias, Cout * 4));
     std::vector<float> hin(in_f), hw((size_t)Cout * Cin * 9);
     for (auto& v : hin) v = (rand() / (float)RAND_MAX) - 0.5f;
     for (auto& v : hw) v = ((rand() / (float)RAND_MAX) - 0.5f) * 0.05f;
@@ -49,6 +68,9 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
           u4 = run<BN, 9, E_RELU, 1, 4, 0>(p, it), u5 = run<BN, 9, E_RELU, 4, 4, 0>(p, it);
     printf("%-28s bufferlds %.1f TF | BM256 %.1f | BM256+bufferlds %.1f | BM256 noload %.1f | BM256 nostore %.1f\n", name, fl / u1 / 1e9, fl / u2 / 1e9,
            fl / u3 / 1e9, fl / u4 / 1e9, fl / u5 / 1e9);
+    float w0 = run_wino<0>(p, it), w1 = run_wino<1>(p, it), w2 = run_wino<2>(p, it), w4 = run_wino<4>(p, it), w7 = run_wino<7>(p, it);
+    printf("%-28s WINOGRAD %.3f ms = %.1f TF-equivalent (direct FLOPs) | noload %.1f | nobarrier %.1f | nostore %.1f | none %.1f\n", name, w0,
+           fl / w0 / 1e9, fl / w1 / 1e9, fl / w2 / 1e9, fl / w4 / 1e9, fl / w7 / 1e9);
     printf("%-28s base %.3f ms %.1f TF | noload %.1f | nobarrier %.1f | noload+nobar %.1f | nostore %.1f | none %.1f TF  (WGs=%d)\n", name, t0,
            fl / t0 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9, fl / t3 / 1e9, fl / t4 / 1e9, fl / t7 / 1e9,
            p.tiles_x * p.tiles_y * B * (Cout / BN));
