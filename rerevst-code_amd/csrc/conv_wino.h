@@ -23,14 +23,46 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
+#include <type_traits>
 #include "conv_mfma.h"
 
-#define WINO_RAW_BYTES 24576            /* 18*18 pixels * 64 B, rounded up to 6 x 256 pieces */
+#define WINO_RAW_BYTES 24576            /* 18*18 pixels * 64 B = 1296 pieces, rounded up to 6 x 256 */
 #define WINO_U_BYTES 32768              /* 16 positions * 32 couts * 16 channels * 4 B */
-#define WINO_SMEM_BYTES (2 * WINO_RAW_BYTES + 2 * WINO_U_BYTES)
+#define WINO_SMEM_BYTES (3 * WINO_RAW_BYTES + 2 * WINO_U_BYTES)   /* 136 KB: one workgroup per CU */
+
+// LDS reads of the hand-pipelined main loop: issued early by inline asm, released by counted
+// s_waitcnt lgkmcnt(N) (LDS returns in order), so the single wave per SIMD never parks on LDS latency.
+__device__ __forceinline__ f32x4 lds_rd128(unsigned addr) {
+    f32x4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_release2(f32x4& a, f32x4& b) {   // a, b become valid here
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_release4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// reads issued in main-loop iteration i: U fragments of position i+2 (2) and, for i<8, two patch pieces
+__host__ __device__ constexpr int wino_issued(int i) { return (i + 2 < 16 ? 2 : 0) + (i < 8 ? 2 : 0); }
+// LDS reads younger than U(i) when iteration i waits for it
+__host__ __device__ constexpr int wino_younger(int i) {
+    return i == 0 ? 2 + wino_issued(0)
+         : i == 1 ? wino_issued(0) + wino_issued(1)
+                  : (i - 2 < 8 ? 2 : 0) + wino_issued(i - 1) + wino_issued(i);
+}
 
 template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256) void conv_wino_k(const ConvP p) {
+__global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, t = lane & 15, q = lane >> 4;
@@ -43,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_wino_k(const ConvP p) {
     const int b = bx / p.tiles_y;
     const int n_tile = blockIdx.y;
     const int y0 = ty * 16, x0 = tx * 16;
-    const int nchunks = p.Cin >> 4;
+    const int nchunks = p.Cin >> 4;      // even (Cin >= 64)
 
     const float* in_b = p.in + (size_t)b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
     int asrc[6];
@@ -58,26 +90,30 @@ __global__ __launch_bounds__(256) void conv_wino_k(const ConvP p) {
     }
     const float* w_tile = p.wpk + (size_t)n_tile * nchunks * (16 * 32 * 16);
 
-    auto stage = [&](int chunk) {
-        char* rdst = smem + (chunk & 1) * WINO_RAW_BYTES;
-        char* udst = smem + 2 * WINO_RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
+    auto stage_u = [&](int chunk) {
+        char* udst = smem + 3 * WINO_RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
 #pragma unroll
         for (int it = 0; it < 8; ++it) bufld16(w_tile, udst + (it * 256 + wave * 64) * 16, tid * 16 + it * 4096, chunk * WINO_U_BYTES);
+    };
+    auto stage_raw = [&](int chunk) {
+        char* rdst = smem + (chunk % 3) * WINO_RAW_BYTES;
 #pragma unroll
-        for (int it = 0; it < 6; ++it) bufld16(in_b, rdst + (it * 256 + wave * 64) * 16, asrc[it], chunk * 64);
+        for (int it = 0; it < 6; ++it)
+            if (it < 5 || wave == 0) bufld16(in_b, rdst + (it * 256 + wave * 64) * 16, asrc[it], chunk * 64);
     };
 
-    // LDS byte offsets of this lane's 4x4 raw patch (pixel index pp, 16-byte piece q, XOR swizzle)
-    int offD[4][4];
+    // LDS byte addresses: this lane's 4x4 raw patch (pixel pp, 16-byte piece q, XOR swizzle), relative
+    // to the raw buffer; and its U fragment (row = pos*32 + nb*16 + t, (row>>2)&3 == (t>>2)&3)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned offD[16];   // index dx*4 + dy
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
+    for (int dx = 0; dx < 4; ++dx)
 #pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
+        for (int dy = 0; dy < 4; ++dy) {
             const int pp = (4 * wave + 2 * tr + dy) * 18 + 2 * tc + dx;
-            offD[dy][dx] = pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4);
+            offD[dx * 4 + dy] = lds0 + pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4);
         }
-    // U fragment: row = pos*32 + nb*16 + t ; (row>>2)&3 == (t>>2)&3 because 32 | pos*32 and 16 | nb*16
-    const int offU = t * 64 + ((q ^ ((t >> 2) & 3)) << 4);
+    const unsigned offU = lds0 + 3 * WINO_RAW_BYTES + t * 64 + ((q ^ ((t >> 2) & 3)) << 4);
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -85,40 +121,88 @@ __global__ __launch_bounds__(256) void conv_wino_k(const ConvP p) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        if (!(ABL & 2) || chunk == 0) __syncthreads();
-        if (!(ABL & 1) && chunk + 1 < nchunks) stage(chunk + 1);
-        const char* raw = smem + (chunk & 1) * WINO_RAW_BYTES;
-        const char* ub = smem + 2 * WINO_RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
-        // ---- input transform V = B^T d B, in registers (4 channels per lane)
-        f32x4 v[4][4];
-        {
-            f32x4 tmp[4][4];
+    f32x4 va[16], vb[16];   // transformed input B^T d B of the current / next chunk (ping-pong)
+
+    // ---- prologue: chunk 0 (and the raw tile of chunk 1) staged, V(0) computed
+    stage_raw(0);
+    stage_u(0);
+    if (nchunks > 1) stage_raw(1);
+    __syncthreads();
+    {
+        f32x4 d[16];
 #pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const f32x4 d0 = *(const f32x4*)(raw + offD[0][dx]), d1 = *(const f32x4*)(raw + offD[1][dx]);
-                const f32x4 d2 = *(const f32x4*)(raw + offD[2][dx]), d3 = *(const f32x4*)(raw + offD[3][dx]);
-                tmp[0][dx] = d0 - d2; tmp[1][dx] = d1 + d2; tmp[2][dx] = d2 - d1; tmp[3][dx] = d1 - d3;
-            }
+        for (int k = 0; k < 16; ++k) d[k] = *(const f32x4*)(smem + (offD[k] - lds0));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r][0] = tmp[r][0] - tmp[r][2]; v[r][1] = tmp[r][1] + tmp[r][2];
-                v[r][2] = tmp[r][2] - tmp[r][1]; v[r][3] = tmp[r][1] - tmp[r][3];
-            }
+        for (int dx = 0; dx < 4; ++dx) {
+            const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
+            d[dx * 4 + 0] = d0 - d2; d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = d2 - d1; d[dx * 4 + 3] = d1 - d3;
         }
-        // ---- 16 positions x 2 cout blocks x 4 k-steps
 #pragma unroll
-        for (int pos = 0; pos < 16; ++pos) {
-            const f32x4 u0 = *(const f32x4*)(ub + pos * 2048 + offU);
-            const f32x4 u1 = *(const f32x4*)(ub + pos * 2048 + 1024 + offU);
-            const f32x4 vv = v[pos >> 2][pos & 3];
+        for (int r = 0; r < 4; ++r) {   // d[dx*4 + r] = (B^T d)[r][dx]
+            va[r * 4 + 0] = d[0 + r] - d[8 + r]; va[r * 4 + 1] = d[4 + r] + d[8 + r];
+            va[r * 4 + 2] = d[8 + r] - d[4 + r]; va[r * 4 + 3] = d[4 + r] - d[12 + r];
+        }
+    }
+
+    // One chunk: MFMAs of chunk c with V(c) = vcur, while the raw patch of chunk c+1 is read and
+    // transformed into vnext.  Issue order per iteration i: U(i+2) x2, then (i<8) patch pieces 2i, 2i+1.
+    auto chunk_body = [&](int c, f32x4 (&vcur)[16], f32x4 (&vnext)[16]) {
+        if (!(ABL & 1)) {
+            if (c + 1 < nchunks) stage_u(c + 1);
+            if (c + 2 < nchunks) stage_raw(c + 2);
+        }
+        const unsigned ub = offU + (c & 1) * WINO_U_BYTES;
+        const unsigned rb = ((c + 1) % 3) * WINO_RAW_BYTES;
+        f32x4 u[4][2];       // U fragments in flight, slot = pos & 3
+        f32x4 d[16];         // raw patch of the next chunk, index dx*4 + dy; becomes B^T d column by column
+        u[0][0] = lds_rd128(ub); u[0][1] = lds_rd128(ub + 1024);
+        u[1][0] = lds_rd128(ub + 2048); u[1][1] = lds_rd128(ub + 2048 + 1024);
+        static_for([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (i + 2 < 16) {
+                u[(i + 2) & 3][0] = lds_rd128(ub + (i + 2) * 2048);
+                u[(i + 2) & 3][1] = lds_rd128(ub + (i + 2) * 2048 + 1024);
+            }
+            if (i < 8) {
+                d[2 * i] = lds_rd128(offD[2 * i] + rb);
+                d[2 * i + 1] = lds_rd128(offD[2 * i + 1] + rb);
+            }
+            // U(i) is complete when at most wino_younger(i) younger reads are outstanding; in-order
+            // return also completes every patch piece issued before U(i), i.e. pieces < 2(i-2)
+            if constexpr (i >= 4 && i <= 10 && (i % 2) == 0) {
+                // column dx = (i-4)/2 of the patch (pieces 4dx..4dx+3, issued in iterations 2dx, 2dx+1) is complete
+                constexpr int dx = (i - 4) / 2;
+                lds_release4<wino_younger(i)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
+                lds_release2<wino_younger(i)>(u[i & 3][0], u[i & 3][1]);
+            } else {
+                lds_release2<wino_younger(i)>(u[i & 3][0], u[i & 3][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 vv = vcur[i];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[s], vv[s], acc[pos][0], 0, 0, 0);
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[s], vv[s], acc[pos][1], 0, 0, 0);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3][0][s], vv[s], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3][1][s], vv[s], acc[i][1], 0, 0, 0);
             }
-        }
+            // input transform of the next chunk, sliced under the MFMAs
+            if constexpr (i >= 4 && i <= 10 && (i % 2) == 0) {
+                constexpr int dx = (i - 4) / 2;
+                const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
+                d[dx * 4 + 0] = d0 - d2; d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = d2 - d1; d[dx * 4 + 3] = d1 - d3;
+            }
+            if constexpr (i >= 11 && i <= 14) {
+                constexpr int r = i - 11;
+                vnext[r * 4 + 0] = d[0 + r] - d[8 + r]; vnext[r * 4 + 1] = d[4 + r] + d[8 + r];
+                vnext[r * 4 + 2] = d[8 + r] - d[4 + r]; vnext[r * 4 + 3] = d[4 + r] - d[12 + r];
+            }
+        }, std::make_integer_sequence<int, 16>{});
+    };
+
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk_body(c, va, vb);
+        if (!(ABL & 2)) __syncthreads();      // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
+        chunk_body(c + 1, vb, va);
+        if (!(ABL & 2)) __syncthreads();
     }
 
     // ---- output transform + fused epilogue (all in registers)
@@ -210,20 +294,21 @@ __global__ __launch_bounds__(256) void conv_wino_k(const ConvP p) {
 }
 
 // Weight transform U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], packed as
-// [Cout/32][Cin/16][pos 16][32 couts][16 floats, 16-byte pieces XOR (cout>>2)&3].
+// [Cout/32][Cin/CH][pos 16][32 couts][CH floats]; for CH=16 the 16-byte pieces are XOR-swizzled by (cout>>2)&3.
 __global__ void pack_wino_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin) {
+    constexpr int CH = 16;
     const size_t total = (size_t)Cout * Cin * 16;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
-        const int e = r & 3; r >>= 2;
-        const int qs = r & 3; r >>= 2;
+        const int cl = (int)(r % CH); r /= CH;            // stored channel slot inside the chunk
         const int j = r & 31; r >>= 5;
         const int pos = r & 15; r >>= 4;
-        const int nchunks = Cin >> 4;
+        const int nchunks = Cin / CH;
         const int chunk = r % nchunks; r /= nchunks;
         const int n_tile = (int)r;
-        const int qq = qs ^ ((j >> 2) & 3);
-        const int co = n_tile * 32 + j, ci = chunk * 16 + qq * 4 + e;
+        const int e = cl & 3, qs = cl >> 2;
+        const int qq = (CH == 16) ? (qs ^ ((j >> 2) & 3)) : qs;
+        const int co = n_tile * 32 + j, ci = chunk * CH + qq * 4 + e;
         const float* g = w + ((size_t)co * Cin + ci) * 9;
         const int pr = pos >> 2, pc = pos & 3;
         float rowv[3];   // (G g)[pr][kx]
