@@ -19,7 +19,10 @@
 //    positions, so A^T M A, bias, activation, saved-stat normalise, residual, AdaIN and the 2x2 max
 //    pool (the Winograd output tile IS the pooling window) are all in-register; stores are 16-byte.
 //  * per 16-channel chunk: one barrier, 18x18x16 raw halo + 16x32x16 U block staged by buffer_load..lds,
-//    double buffered (114 KB LDS, one workgroup per CU).
+//    double buffered (112 KB LDS, one workgroup per CU); the raw tile is staged TWO chunks ahead so that
+//    the patch reads + B^T d B of chunk c+1 are sliced under the MFMAs of chunk c.
+//  * workgroups are persistent (grid = #CUs) and walk the (pixel tile, cout slab) work items; the first
+//    tiles of the next item are requested before the epilogue of the current one.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,7 +32,7 @@
 
 #define WINO_RAW_BYTES 24576            /* 18*18 pixels * 64 B = 1296 pieces, rounded up to 6 x 256 */
 #define WINO_U_BYTES 32768              /* 16 positions * 32 couts * 16 channels * 4 B */
-#define WINO_SMEM_BYTES (3 * WINO_RAW_BYTES + 2 * WINO_U_BYTES)   /* 136 KB: one workgroup per CU */
+#define WINO_SMEM_BYTES (2 * WINO_RAW_BYTES + 2 * WINO_U_BYTES)   /* 112 KB: one workgroup per CU */
 
 // LDS reads of the hand-pipelined main loop: issued early by inline asm, released by counted
 // s_waitcnt lgkmcnt(N) (LDS returns in order), so the single wave per SIMD never parks on LDS latency.
@@ -67,36 +70,42 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, t = lane & 15, q = lane >> 4;
     const int tr = t >> 3, tc = t & 7;
-
-    int bx = blockIdx.x;
-    const int tx = bx % p.tiles_x;
-    bx /= p.tiles_x;
-    const int ty = bx % p.tiles_y;
-    const int b = bx / p.tiles_y;
-    const int n_tile = blockIdx.y;
-    const int y0 = ty * 16, x0 = tx * 16;
     const int nchunks = p.Cin >> 4;      // even (Cin >= 64)
+    const int n_ntiles = p.Cout >> 5;
+    const int total = p.tiles_x * p.tiles_y * p.B * n_ntiles;
 
-    const float* in_b = p.in + (size_t)b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
+    // ---- per-tile state of the tile being LOADED (the persistent loop prefetches one tile ahead)
+    int y0 = 0, x0 = 0, b = 0, n_tile = 0;
+    const float* in_b = p.in;
+    const float* w_tile = p.wpk;
     int asrc[6];
+    auto setup = [&](int tile) {
+        n_tile = tile % n_ntiles;          // the cout slabs of one pixel tile run side by side: its raw input stays in L2
+        int r = tile / n_ntiles;
+        const int tx = r % p.tiles_x;
+        r /= p.tiles_x;
+        const int ty = r % p.tiles_y;
+        b = r / p.tiles_y;
+        y0 = ty * 16; x0 = tx * 16;
+        in_b = p.in + (size_t)b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
+        w_tile = p.wpk + (size_t)n_tile * nchunks * (16 * 32 * 16);
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
-        const int e = it * 256 + tid;
-        int pp = e >> 2;
-        const int qq = e & 3;
-        if (pp >= 324) pp = 0;
-        const int hy = pp / 18, hx = pp - hy * 18;
-        asrc[it] = (((y0 + hy) * (p.Wi + 2) + (x0 + hx)) * p.Cin + 4 * (qq ^ ((pp >> 2) & 3))) * 4;
-    }
-    const float* w_tile = p.wpk + (size_t)n_tile * nchunks * (16 * 32 * 16);
-
+        for (int it = 0; it < 6; ++it) {
+            const int e = it * 256 + tid;
+            int pp = e >> 2;
+            const int qq = e & 3;
+            if (pp >= 324) pp = 0;
+            const int hy = pp / 18, hx = pp - hy * 18;
+            asrc[it] = (((y0 + hy) * (p.Wi + 2) + (x0 + hx)) * p.Cin + 4 * (qq ^ ((pp >> 2) & 3))) * 4;
+        }
+    };
     auto stage_u = [&](int chunk) {
-        char* udst = smem + 3 * WINO_RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
+        char* udst = smem + 2 * WINO_RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
 #pragma unroll
         for (int it = 0; it < 8; ++it) bufld16(w_tile, udst + (it * 256 + wave * 64) * 16, tid * 16 + it * 4096, chunk * WINO_U_BYTES);
     };
     auto stage_raw = [&](int chunk) {
-        char* rdst = smem + (chunk % 3) * WINO_RAW_BYTES;
+        char* rdst = smem + (chunk & 1) * WINO_RAW_BYTES;
 #pragma unroll
         for (int it = 0; it < 6; ++it)
             if (it < 5 || wave == 0) bufld16(in_b, rdst + (it * 256 + wave * 64) * 16, asrc[it], chunk * 64);
@@ -113,46 +122,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
             const int pp = (4 * wave + 2 * tr + dy) * 18 + 2 * tc + dx;
             offD[dx * 4 + dy] = lds0 + pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4);
         }
-    const unsigned offU = lds0 + 3 * WINO_RAW_BYTES + t * 64 + ((q ^ ((t >> 2) & 3)) << 4);
+    const unsigned offU = lds0 + 2 * WINO_RAW_BYTES + t * 64 + ((q ^ ((t >> 2) & 3)) << 4);
 
     f32x4 acc[16][2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     f32x4 va[16], vb[16];   // transformed input B^T d B of the current / next chunk (ping-pong)
-
-    // ---- prologue: chunk 0 (and the raw tile of chunk 1) staged, V(0) computed
-    stage_raw(0);
-    stage_u(0);
-    if (nchunks > 1) stage_raw(1);
-    __syncthreads();
-    {
-        f32x4 d[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = *(const f32x4*)(smem + (offD[k] - lds0));
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
-            const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
-            d[dx * 4 + 0] = d0 - d2; d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = d2 - d1; d[dx * 4 + 3] = d1 - d3;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {   // d[dx*4 + r] = (B^T d)[r][dx]
-            va[r * 4 + 0] = d[0 + r] - d[8 + r]; va[r * 4 + 1] = d[4 + r] + d[8 + r];
-            va[r * 4 + 2] = d[8 + r] - d[4 + r]; va[r * 4 + 3] = d[4 + r] - d[12 + r];
-        }
-    }
 
     // One chunk: MFMAs of chunk c with V(c) = vcur, while the raw patch of chunk c+1 is read and
     // transformed into vnext.  Issue order per iteration i: U(i+2) x2, then (i<8) patch pieces 2i, 2i+1.
     auto chunk_body = [&](int c, f32x4 (&vcur)[16], f32x4 (&vnext)[16]) {
         if (!(ABL & 1)) {
-            if (c + 1 < nchunks) stage_u(c + 1);
-            if (c + 2 < nchunks) stage_raw(c + 2);
+            if (c + 1 < nchunks) stage_u(c + 1);          // U buffer (c+1)&1: last read in iteration c-1
+            if (c + 2 < nchunks) stage_raw(c + 2);        // raw buffer c&1: its patch was read in iteration c-1
         }
         const unsigned ub = offU + (c & 1) * WINO_U_BYTES;
-        const unsigned rb = ((c + 1) % 3) * WINO_RAW_BYTES;
+        const unsigned rb = ((c + 1) & 1) * WINO_RAW_BYTES;
         f32x4 u[4][2];       // U fragments in flight, slot = pos & 3
         f32x4 d[16];         // raw patch of the next chunk, index dx*4 + dy; becomes B^T d column by column
         u[0][0] = lds_rd128(ub); u[0][1] = lds_rd128(ub + 1024);
@@ -198,96 +181,136 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
         }, std::make_integer_sequence<int, 16>{});
     };
 
-    for (int c = 0; c < nchunks; c += 2) {
-        chunk_body(c, va, vb);
-        if (!(ABL & 2)) __syncthreads();      // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
-        chunk_body(c + 1, vb, va);
-        if (!(ABL & 2)) __syncthreads();
+    // ---- persistent loop over (pixel tile, cout slab) work items; the next item's first tiles are in
+    // flight while the current item's epilogue runs
+    int tile = blockIdx.x;
+    if (tile < total) {
+        setup(tile);
+        stage_raw(0);
+        stage_u(0);
+        stage_raw(1);
     }
+    while (tile < total) {
+        const int e_y0 = y0, e_x0 = x0, e_b = b, e_ntile = n_tile;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                      // raw(0), U(0), raw(1) landed
+        {   // V(0)
+            f32x4 d[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k] = *(const f32x4*)(smem + (offD[k] - lds0));
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
+                d[dx * 4 + 0] = d0 - d2; d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = d2 - d1; d[dx * 4 + 3] = d1 - d3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // d[dx*4 + r] = (B^T d)[r][dx]
+                va[r * 4 + 0] = d[0 + r] - d[8 + r]; va[r * 4 + 1] = d[4 + r] + d[8 + r];
+                va[r * 4 + 2] = d[8 + r] - d[4 + r]; va[r * 4 + 3] = d[4 + r] - d[12 + r];
+            }
+        }
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk_body(c, va, vb);
+            if (!(ABL & 2)) __syncthreads();      // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
+            chunk_body(c + 1, vb, va);
+            if (!(ABL & 2)) __syncthreads();
+        }
+        // every LDS buffer is free now: start the next work item's loads before this item's epilogue
+        tile += gridDim.x;
+        if (tile < total && !(ABL & 1)) {
+            setup(tile);
+            stage_raw(0);
+            stage_u(0);
+            stage_raw(1);
+        }
 
-    // ---- output transform + fused epilogue (all in registers)
-    const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
-    float* out_b = p.out + (size_t)b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
-    const float* res_b = nullptr;
-    if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
-    const int yb = y0 + 4 * wave + 2 * tr, xb = x0 + 2 * tc;
+        // ---- output transform + fused epilogue (all in registers)
+        const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
+        float* out_b = p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
+        const float* res_b = nullptr;
+        if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
+        const int yb = e_y0 + 4 * wave + 2 * tr, xb = e_x0 + 2 * tc;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int co = n_tile * 32 + nb * 16 + 4 * q;
-        f32x4 Y[2][2];
-        {
-            f32x4 T[2][4];
+        for (int nb = 0; nb < 2; ++nb) {
+            const int co = e_ntile * 32 + nb * 16 + 4 * q;
+            f32x4 Y[2][2];
+            {
+                f32x4 T[2][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                T[0][c] = acc[0 + c][nb] + acc[4 + c][nb] + acc[8 + c][nb];
-                T[1][c] = acc[4 + c][nb] - acc[8 + c][nb] - acc[12 + c][nb];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                Y[i][0] = T[i][0] + T[i][1] + T[i][2];
-                Y[i][1] = T[i][1] - T[i][2] - T[i][3];
-            }
-        }
-        const f32x4 bias = *(const f32x4*)(p.bias + co);
-        f32x4 m1, r1, lo1, hi1, m2, r2, lo2, hi2, smean, sstd;
-        if (EPI & E_NORM1) {
-            m1 = *(const f32x4*)(p.n1 + co); r1 = *(const f32x4*)(p.n1 + p.Cout + co);
-            lo1 = *(const f32x4*)(p.n1 + 2 * p.Cout + co); hi1 = *(const f32x4*)(p.n1 + 3 * p.Cout + co);
-        }
-        if (EPI & E_NORM2) {
-            m2 = *(const f32x4*)(p.n2 + co); r2 = *(const f32x4*)(p.n2 + p.Cout + co);
-            lo2 = *(const f32x4*)(p.n2 + 2 * p.Cout + co); hi2 = *(const f32x4*)(p.n2 + 3 * p.Cout + co);
-            smean = *(const f32x4*)(p.sty + co); sstd = *(const f32x4*)(p.sty + p.Cout + co);
-        }
-        f32x4 pooled;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int y = yb + i, x = xb + j;
-                const bool valid = (y < p.H) && (x < p.W);
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float tv = Y[i][j][e] + bias[e];
-                    if (EPI & E_RELU) tv = fmaxf(tv, 0.f);
-                    if (EPI & E_LRELU) tv = (tv >= 0.f) ? tv : tv * 0.2f;
-                    if (EPI & E_NORM1) {
-                        tv = (tv - m1[e]) * r1[e];
-                        tv = fminf(hi1[e], fmaxf(lo1[e], tv));
-                    }
-                    o[e] = tv;
+                for (int c = 0; c < 4; ++c) {
+                    T[0][c] = acc[0 + c][nb] + acc[4 + c][nb] + acc[8 + c][nb];
+                    T[1][c] = acc[4 + c][nb] - acc[8 + c][nb] - acc[12 + c][nb];
                 }
-                if (EPI & (E_RES | E_RES_UPS)) {
-                    if (valid) {
-                        const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
-                        o += *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + co);
-                    }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Y[i][0] = T[i][0] + T[i][1] + T[i][2];
+                    Y[i][1] = T[i][1] - T[i][2] - T[i][3];
                 }
-                if (EPI & E_NORM2) {
+            }
+            const f32x4 bias = *(const f32x4*)(p.bias + co);
+            f32x4 m1, r1, lo1, hi1, m2, r2, lo2, hi2, smean, sstd;
+            if (EPI & E_NORM1) {
+                m1 = *(const f32x4*)(p.n1 + co); r1 = *(const f32x4*)(p.n1 + p.Cout + co);
+                lo1 = *(const f32x4*)(p.n1 + 2 * p.Cout + co); hi1 = *(const f32x4*)(p.n1 + 3 * p.Cout + co);
+            }
+            if (EPI & E_NORM2) {
+                m2 = *(const f32x4*)(p.n2 + co); r2 = *(const f32x4*)(p.n2 + p.Cout + co);
+                lo2 = *(const f32x4*)(p.n2 + 2 * p.Cout + co); hi2 = *(const f32x4*)(p.n2 + 3 * p.Cout + co);
+                smean = *(const f32x4*)(p.sty + co); sstd = *(const f32x4*)(p.sty + p.Cout + co);
+            }
+            f32x4 pooled;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int y = yb + i, x = xb + j;
+                    const bool valid = (y < p.H) && (x < p.W);
+                    f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float tv = (o[e] - m2[e]) * r2[e];
-                        tv = fminf(hi2[e], fmaxf(lo2[e], tv));
-                        o[e] = tv * sstd[e] + smean[e];
+                        float tv = Y[i][j][e] + bias[e];
+                        if (EPI & E_RELU) tv = fmaxf(tv, 0.f);
+                        if (EPI & E_LRELU) tv = (tv >= 0.f) ? tv : tv * 0.2f;
+                        if (EPI & E_NORM1) {
+                            tv = (tv - m1[e]) * r1[e];
+                            tv = fminf(hi1[e], fmaxf(lo1[e], tv));
+                        }
+                        o[e] = tv;
                     }
-                }
-                if (EPI & E_POOL) {
-                    if (i == 0 && j == 0) pooled = o;
-                    else {
+                    if (EPI & (E_RES | E_RES_UPS)) {
+                        if (valid) {
+                            const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
+                            o += *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + co);
+                        }
+                    }
+                    if (EPI & E_NORM2) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], o[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            float tv = (o[e] - m2[e]) * r2[e];
+                            tv = fminf(hi2[e], fmaxf(lo2[e], tv));
+                            o[e] = tv * sstd[e] + smean[e];
+                        }
                     }
-                } else if (valid) {
-                    if (ABL & 4) { if (o[0] == 123.456f) out_b[co] = o[0]; }
-                    else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
+                    if (EPI & E_POOL) {
+                        if (i == 0 && j == 0) pooled = o;
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], o[e]);
+                        }
+                    } else if (valid) {
+                        if (ABL & 4) { if (o[0] == 123.456f) out_b[co] = o[0]; }
+                        else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
+                    }
                 }
-            }
-        if (EPI & E_POOL) {
-            const int y2 = yb >> 1, x2 = xb >> 1;
-            if (y2 < Ho && x2 < Wo) {
-                if (ABL & 4) { if (pooled[0] == 123.456f) out_b[co] = pooled[0]; }
-                else *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
+            if (EPI & E_POOL) {
+                const int y2 = yb >> 1, x2 = xb >> 1;
+                if (y2 < Ho && x2 < Wo) {
+                    if (ABL & 4) { if (pooled[0] == 123.456f) out_b[co] = pooled[0]; }
+                    else *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
+                }
             }
         }
     }

@@ -101,6 +101,7 @@ struct rrv_ctx {
     int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
     float* d_outf = nullptr; size_t d_outf_cap = 0;
+    int n_cus = 256;
     bool use_wino = true;                      // Winograd F(2x2,3x3) for the 3x3 layers that have a transformed pack
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -246,7 +247,11 @@ int conv(rrv_handle h, const ConvCall& c) {
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
     if (c.out->H != oh || c.out->W != ow) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
     if (c.ups || wino) { p.tiles_y = (c.H + 15) / 16; }
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B * (c.ups ? 2 : 1)), (unsigned)(w.Cout / (wino ? 32 : w.BN)));
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B * (c.ups ? 2 : 1)), (unsigned)(w.Cout / w.BN));
+    if (wino) {   // persistent workgroups, one per CU, walking tiles_x*tiles_y*B*(Cout/32) work items
+        const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B * (w.Cout / 32));
+        grid = dim3(items < (unsigned)h->n_cus ? items : (unsigned)h->n_cus, 1);
+    }
     const double px = (double)c.B * c.H * c.W;
     // executed multiply-adds: ups2 folds 9 taps into 4; Winograd F(2x2,3x3) needs 16 per 2x2 outputs (= 4 per pixel)
     const double flops = 2.0 * px * w.Cout * w.Cin * ((c.ups || wino) ? 4 : w.taps);
@@ -611,6 +616,10 @@ int rrv_create(int device, rrv_handle* out) {
     }
     h->stream = h->streams[0];
     if (const char* e = getenv("RRV_WINO")) h->use_wino = (e[0] != '0');
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
+    }
     *out = h;
     return RRV_OK;
 }

@@ -29,7 +29,8 @@ float run(ConvP p, int iters) {
 template <int ABL>
 float run_wino(ConvP p, int iters) {
     p.tiles_y = (p.H + 15) / 16;
-    dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / 32);
+    int items = p.tiles_x * p.tiles_y * p.B * (p.Cout / 32);
+    dim3 grid(items < 256 ? items : 256, 1);
     CK(hipFuncSetAttribute((const void*)conv_wino_k<E_RELU, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_SMEM_BYTES));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
