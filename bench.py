@@ -125,10 +125,14 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel from the live per-launch events ---------------
-        agg = {}
-        for name, ms, fl, by in rows:
+        agg, layers = {}, {}
+        for full, ms, fl, by in rows:
+            name = full.split("@")[0]
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+            if "@" in full:
+                l = layers.setdefault(full, [0, 0.0, 0.0])
+                l[0] += 1; l[1] += ms; l[2] += fl
         roof, kern = None, []
         if agg:
             tot_ms = sum(a[1] for a in agg.values())
@@ -172,6 +176,9 @@ def main():
                                       % (NF, S, S, P, P), "frames_per_step_per_gpu": B, "batches_in_flight": args.pipeline, "sampled_frames": len(video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
                "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu, "prep_seconds_rank0": round(prep_s, 3), "kernels": kern}
+        if os.environ.get("RRV_BENCH_LAYERS"):
+            out["layers"] = [{"layer": k, "ms_per_frame": round(v[1] / nprof / B, 4), "tflops_executed": round(v[2] / v[1] / 1e9, 1)}
+                             for k, v in sorted(layers.items(), key=lambda kv: -kv[1][1])]
         print(json.dumps(out), flush=True)
     model.close()
     if world > 1:

@@ -32,7 +32,8 @@
 
 #define WINO_RAW_BYTES 24576            /* 18*18 pixels * 64 B = 1296 pieces, rounded up to 6 x 256 */
 #define WINO_U_BYTES 32768              /* 16 positions * 32 couts * 16 channels * 4 B */
-#define WINO_SMEM_BYTES (2 * WINO_RAW_BYTES + 2 * WINO_U_BYTES)   /* 112 KB: one workgroup per CU */
+#define WINO_PAR_BYTES 2048             /* per-channel epilogue parameters of the item's 32 couts: 11 vectors x 128 B */
+#define WINO_SMEM_BYTES (2 * WINO_RAW_BYTES + 2 * WINO_U_BYTES + WINO_PAR_BYTES)   /* 114 KB: one workgroup per CU */
 
 // LDS reads of the hand-pipelined main loop: issued early by inline asm, released by counted
 // s_waitcnt lgkmcnt(N) (LDS returns in order), so the single wave per SIMD never parks on LDS latency.
@@ -109,6 +110,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
 #pragma unroll
         for (int it = 0; it < 6; ++it)
             if (it < 5 || wave == 0) bufld16(in_b, rdst + (it * 256 + wave * 64) * 16, asrc[it], chunk * 64);
+    };
+
+    // per-channel epilogue parameters of the item's cout slab, parked in LDS while the K loop runs:
+    // rows of 32 floats: 0 bias | 1-4 n1 (mean, rstd, lo, hi) | 5-8 n2 | 9-10 style mean, std
+    char* const par = smem + 2 * WINO_RAW_BYTES + 2 * WINO_U_BYTES;
+    auto stage_params = [&](int ntile) {
+        if (wave < 2) {
+            const int e = tid;                       // 16-byte piece: row e>>3, floats 4*(e&7)..
+            const int row = e >> 3, col = (e & 7) * 4;
+            const float* src = p.bias;
+            int off = ntile * 32 + col;
+            if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off += (EPI & E_NORM1) ? (row - 1) * p.Cout : 0; }
+            if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off += (EPI & E_NORM2) ? (row - 5) * p.Cout : 0; }
+            if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off += (EPI & E_NORM2) ? (row - 9) * p.Cout : 0; }
+            if (row > 10) { src = p.bias; off = ntile * 32; }
+            glds16(src + off, par + wave * 1024);
+        }
     };
 
     // LDS byte addresses: this lane's 4x4 raw patch (pixel pp, 16-byte piece q, XOR swizzle), relative
@@ -190,12 +208,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
         stage_u(0);
         stage_raw(1);
     }
+    int par_ntile = -1;
     while (tile < total) {
         const int e_y0 = y0, e_x0 = x0, e_b = b, e_ntile = n_tile;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (par_ntile != e_ntile) {            // (never re-staged when gridDim.x is a multiple of the slab count)
+            if (par_ntile >= 0) __syncthreads();   // slower waves may still read the old slab's parameters
+            stage_params(e_ntile);                 // lands before the first K-loop barrier
+            par_ntile = e_ntile;
+        }
         __syncthreads();                      // raw(0), U(0), raw(1) landed
         {   // V(0)
             f32x4 d[16];
@@ -233,6 +257,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
         const float* res_b = nullptr;
         if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
         const int yb = e_y0 + 4 * wave + 2 * tr, xb = e_x0 + 2 * tc;
+        f32x4 resv[2][2][2];     // residual values requested before the output transform hides their latency
+        if (EPI & (E_RES | E_RES_UPS)) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int y = yb + i, x = xb + j;
+                        const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
+                        resv[nb][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (y < p.H && x < p.W)
+                            resv[nb][i][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + nb * 16 + 4 * q);
+                    }
+        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             const int co = e_ntile * 32 + nb * 16 + 4 * q;
@@ -250,16 +289,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
                     Y[i][1] = T[i][1] - T[i][2] - T[i][3];
                 }
             }
-            const f32x4 bias = *(const f32x4*)(p.bias + co);
+            const char* pl = par + (nb * 16 + 4 * q) * 4;      // this lane's 4 channels inside a 128-byte parameter row
+            const f32x4 bias = *(const f32x4*)(pl);
             f32x4 m1, r1, lo1, hi1, m2, r2, lo2, hi2, smean, sstd;
             if (EPI & E_NORM1) {
-                m1 = *(const f32x4*)(p.n1 + co); r1 = *(const f32x4*)(p.n1 + p.Cout + co);
-                lo1 = *(const f32x4*)(p.n1 + 2 * p.Cout + co); hi1 = *(const f32x4*)(p.n1 + 3 * p.Cout + co);
+                m1 = *(const f32x4*)(pl + 128); r1 = *(const f32x4*)(pl + 256);
+                lo1 = *(const f32x4*)(pl + 384); hi1 = *(const f32x4*)(pl + 512);
             }
             if (EPI & E_NORM2) {
-                m2 = *(const f32x4*)(p.n2 + co); r2 = *(const f32x4*)(p.n2 + p.Cout + co);
-                lo2 = *(const f32x4*)(p.n2 + 2 * p.Cout + co); hi2 = *(const f32x4*)(p.n2 + 3 * p.Cout + co);
-                smean = *(const f32x4*)(p.sty + co); sstd = *(const f32x4*)(p.sty + p.Cout + co);
+                m2 = *(const f32x4*)(pl + 640); r2 = *(const f32x4*)(pl + 768);
+                lo2 = *(const f32x4*)(pl + 896); hi2 = *(const f32x4*)(pl + 1024);
+                smean = *(const f32x4*)(pl + 1152); sstd = *(const f32x4*)(pl + 1280);
             }
             f32x4 pooled;
 #pragma unroll
@@ -280,12 +320,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
                         }
                         o[e] = tv;
                     }
-                    if (EPI & (E_RES | E_RES_UPS)) {
-                        if (valid) {
-                            const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
-                            o += *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + co);
-                        }
-                    }
+                    if (EPI & (E_RES | E_RES_UPS)) o += resv[nb][i][j];
                     if (EPI & E_NORM2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {

@@ -49,7 +49,7 @@ struct ConvW {           // one convolution's device weights
     int Cout = 0, Cin = 0, taps = 0, BN = 0;
 };
 
-struct ProfEntry { const char* name; hipEvent_t e0, e1; double flops, bytes; float ms; };
+struct ProfEntry { std::string name; hipEvent_t e0, e1; double flops, bytes; float ms; };
 
 // VGG conv indices and (cin,cout)
 const int VGG_IDX[9] = {0, 2, 5, 7, 10, 12, 14, 16, 19};
@@ -259,6 +259,11 @@ int conv(rrv_handle h, const ConvCall& c) {
                                 (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps);
     hipStream_t s = h->stream;
     ConvFn fn = k->fn;
+    if (h->profiling) {   // "<kernel>@CinxCout@HxW": bench.py groups by the part before '@'
+        char nm[160];
+        snprintf(nm, sizeof nm, "%s@%dx%d@%dx%d", k->name, w.Cin, w.Cout, c.H, c.W);
+        return launch(h, nm, flops, bytes, [&] { fn(p, grid, s); });
+    }
     return launch(h, k->name, flops, bytes, [&] { fn(p, grid, s); });
 }
 
@@ -955,7 +960,7 @@ int rrv_profile_count(rrv_handle h) { return h ? (int)h->prof.size() : RRV_E_ARG
 int rrv_profile_entry(rrv_handle h, int i, const char** name, float* ms, double* flops, double* bytes) {
     if (!h || i < 0 || i >= (int)h->prof.size()) return RRV_E_ARG;
     const ProfEntry& e = h->prof[i];
-    if (name) *name = e.name;
+    if (name) *name = e.name.c_str();
     if (ms) *ms = e.ms;
     if (flops) *flops = e.flops;
     if (bytes) *bytes = e.bytes;
