@@ -113,12 +113,15 @@ int rrv_set_pipeline(rrv_handle h, int n_slots);
 
 /* Per-launch timing with HIP events recorded on the handle's own stream.
  * rrv_profile_begin() clears the log and starts bracketing every kernel launch with
- * events; rrv_profile_end() syncs and freezes the log.  Entry i: kernel name, elapsed ms,
- * algorithmic FLOPs and algorithmic HBM bytes of that launch. */
+ * events; rrv_profile_end() syncs and freezes the log.  Entry i: kernel name (with "@CinxCout@HxW"
+ * for convolutions), elapsed ms, ALGORITHMIC FLOPs (the reference's direct convolution:
+ * 2*B*H*W*Cin*Cout*taps) and algorithmic HBM bytes of that launch, and the FLOPs the kernel actually
+ * executes (fewer for the Winograd and upsample-folded kernels). */
 int rrv_profile_begin(rrv_handle h);
 int rrv_profile_end(rrv_handle h);
 int rrv_profile_count(rrv_handle h);
-int rrv_profile_entry(rrv_handle h, int i, const char** name, float* ms, double* flops, double* bytes);
+int rrv_profile_entry(rrv_handle h, int i, const char** name, float* ms, double* flops, double* bytes,
+                      double* flops_executed);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ SYMBOLS = {
     "rrv_profile_end": (C.c_int, [C.c_void_p]),
     "rrv_profile_count": (C.c_int, [C.c_void_p]),
     "rrv_profile_entry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
-                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 

@@ -49,7 +49,7 @@ struct ConvW {           // one convolution's device weights
     int Cout = 0, Cin = 0, taps = 0, BN = 0;
 };
 
-struct ProfEntry { std::string name; hipEvent_t e0, e1; double flops, bytes; float ms; };
+struct ProfEntry { std::string name; hipEvent_t e0, e1; double flops, bytes; float ms; double flops_exec; };
 
 // VGG conv indices and (cin,cout)
 const int VGG_IDX[9] = {0, 2, 5, 7, 10, 12, 14, 16, 19};
@@ -145,9 +145,9 @@ int talloc(rrv_handle h, Tens* t, int B, int H, int W, int C) {
 void tfree(Tens* t) { if (t->p) (void)hipFree(t->p); t->p = nullptr; }
 
 template <typename F>
-int launch(rrv_handle h, const char* name, double flops, double bytes, F&& f) {
+int launch(rrv_handle h, const char* name, double flops, double bytes, F&& f, double flops_exec = -1.0) {
     if (h->profiling) {
-        ProfEntry e{name, nullptr, nullptr, flops, bytes, 0.f};
+        ProfEntry e{name, nullptr, nullptr, flops, bytes, 0.f, flops_exec < 0 ? flops : flops_exec};
         HIPCHK(hipEventCreate(&e.e0)); HIPCHK(hipEventCreate(&e.e1));
         HIPCHK(hipEventRecord(e.e0, h->stream));
         f();
@@ -253,8 +253,10 @@ int conv(rrv_handle h, const ConvCall& c) {
         grid = dim3(items < (unsigned)h->n_cus ? items : (unsigned)h->n_cus, 1);
     }
     const double px = (double)c.B * c.H * c.W;
-    // executed multiply-adds: ups2 folds 9 taps into 4; Winograd F(2x2,3x3) needs 16 per 2x2 outputs (= 4 per pixel)
-    const double flops = 2.0 * px * w.Cout * w.Cin * ((c.ups || wino) ? 4 : w.taps);
+    // algorithmic FLOPs = the reference's direct convolution (taps multiply-adds per output);
+    // executed: ups2 folds 9 taps into 4, Winograd F(2x2,3x3) needs 16 per 2x2 outputs (= 4 per pixel)
+    const double flops = 2.0 * px * w.Cout * w.Cin * w.taps;
+    const double flops_exec = 2.0 * px * w.Cout * w.Cin * ((c.ups || wino) ? 4 : w.taps);
     const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * w.Cin + (double)c.B * oh * ow * w.Cout +
                                 (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps);
     hipStream_t s = h->stream;
@@ -262,9 +264,9 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (h->profiling) {   // "<kernel>@CinxCout@HxW": bench.py groups by the part before '@'
         char nm[160];
         snprintf(nm, sizeof nm, "%s@%dx%d@%dx%d", k->name, w.Cin, w.Cout, c.H, c.W);
-        return launch(h, nm, flops, bytes, [&] { fn(p, grid, s); });
+        return launch(h, nm, flops, bytes, [&] { fn(p, grid, s); }, flops_exec);
     }
-    return launch(h, k->name, flops, bytes, [&] { fn(p, grid, s); });
+    return launch(h, k->name, flops, bytes, [&] { fn(p, grid, s); }, flops_exec);
 }
 
 // ---- weights ----------------------------------------------------------------------------
@@ -957,13 +959,14 @@ int rrv_profile_end(rrv_handle h) {
 
 int rrv_profile_count(rrv_handle h) { return h ? (int)h->prof.size() : RRV_E_ARG; }
 
-int rrv_profile_entry(rrv_handle h, int i, const char** name, float* ms, double* flops, double* bytes) {
+int rrv_profile_entry(rrv_handle h, int i, const char** name, float* ms, double* flops, double* bytes, double* flops_executed) {
     if (!h || i < 0 || i >= (int)h->prof.size()) return RRV_E_ARG;
     const ProfEntry& e = h->prof[i];
     if (name) *name = e.name.c_str();
     if (ms) *ms = e.ms;
     if (flops) *flops = e.flops;
     if (bytes) *bytes = e.bytes;
+    if (flops_executed) *flops_executed = e.flops_exec;
     return RRV_OK;
 }
 

@@ -160,8 +160,8 @@ class Stylization():
         self._chk(self._lib.rrv_profile_end(self._h))
         n = self._lib.rrv_profile_count(self._h)
         rows = []
-        name, ms, fl, by = C.c_char_p(), C.c_float(), C.c_double(), C.c_double()
+        name, ms, fl, by, fx = C.c_char_p(), C.c_float(), C.c_double(), C.c_double(), C.c_double()
         for i in range(n):
-            self._chk(self._lib.rrv_profile_entry(self._h, i, C.byref(name), C.byref(ms), C.byref(fl), C.byref(by)))
-            rows.append((name.value.decode(), ms.value, fl.value, by.value))
+            self._chk(self._lib.rrv_profile_entry(self._h, i, C.byref(name), C.byref(ms), C.byref(fl), C.byref(by), C.byref(fx)))
+            rows.append((name.value.decode(), ms.value, fl.value, by.value, fx.value))
         return rows
