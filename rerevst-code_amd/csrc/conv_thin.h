@@ -102,16 +102,20 @@ struct LastP {
     int tiles_x, tiles_y;
 };
 
+// Matrix-core form: v_mfma_f32_4x4x1_16B_f32 runs 16 independent 4x4 outer products per instruction
+// (lane 4b+i feeds A-row i of block b, lane 4b+j feeds B-column j; D[i][j] of block b = register i of lane
+// 4b+j), so a wave evaluates 64 pixels x 4 output channels per K step with no padding to 16/32 channels:
+// A = the pixel's input value (one lane per pixel), B = w[k][rgb] replicated over the blocks.
+// LDS: 18x18x16-channel halo chunks (double-buffered LDS-DMA) + the whole weight table [tap][chunk][4][16].
 __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
-    // 18x18 halo x 16 channels per stage, XOR-swizzled 16-byte pieces
     __shared__ __attribute__((aligned(16))) float s_in[2][18 * 18 * 16];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float s_w[9 * 4 * 4 * 16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int bx = blockIdx.x;
     const int tx = bx % p.tiles_x;
     bx /= p.tiles_x;
     const int ty = bx % p.tiles_y, b = bx / p.tiles_y;
     const int y0 = ty * 16, x0 = tx * 16;
-    const int py = tid >> 4, px = tid & 15;
     const float* in_b = p.in + (size_t)b * (size_t)(p.H + 2) * (p.W + 2) * 64;
 
     auto stage = [&](int chunk, int buf) {
@@ -122,43 +126,54 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
             bufld16(in_b, (char*)&s_in[buf][0] + (e - (tid & 63)) * 16, off, chunk * 64);
         }
     };
-    float acc[3] = {0.f, 0.f, 0.f};
     stage(0, 0);
+    // weights: p.w is [9][64][4] (tap, cin, rgb-padded); LDS image [tap][chunk][j][16 cin]
+    for (int i = tid; i < 9 * 64 * 4; i += 256) {
+        const int j = i & 3, ci = (i >> 2) & 63, tap = i >> 8;
+        s_w[((tap * 4 + (ci >> 4)) * 4 + j) * 16 + (ci & 15)] = p.w[i];
+    }
+    const int prow = lane >> 4, pcol = lane & 15;   // this lane's pixel as the A operand: wave rows 4w..4w+3
+    const int jb = lane & 3;                        // this lane's output channel as the B operand / D column
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int chunk = 0; chunk < 4; ++chunk) {
         __syncthreads();
         if (chunk + 1 < 4) stage(chunk + 1, (chunk + 1) & 1);
         const char* buf = (const char*)&s_in[chunk & 1][0];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int pp = (4 * wave + prow + ky) * 18 + pcol + kx;
+            const int sw = (pp >> 2) & 3;
+            const float* wt = &s_w[((tap * 4 + chunk) * 4 + jb) * 16];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int pp = (py + ky) * 18 + px + kx;
-                const int sw = (pp >> 2) & 3;
-                const float* wt = p.w + ((ky * 3 + kx) * 64 + chunk * 16) * 4;   // wave-uniform -> scalar loads
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *(const f32x4*)(buf + pp * 64 + ((q ^ sw) << 4));
+                const f32x4 w4 = *(const f32x4*)(wt + q * 4);
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const f32x4 v = *(const f32x4*)(buf + pp * 64 + ((qq ^ sw) << 4));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float* w4 = wt + (qq * 4 + e) * 4;
-                        acc[0] += v[e] * w4[0];
-                        acc[1] += v[e] * w4[1];
-                        acc[2] += v[e] * w4[2];
-                    }
-                }
+                for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s], w4[s], acc[q], 0, 0, 0);
             }
+        }
     }
-    const int y = y0 + py, x = x0 + px;
-    if (y < p.H && x < p.W) {
+    const f32x4 r = acc[0] + acc[1] + acc[2] + acc[3];
+    // D: register i of lane 4*blk + j  =  pixel 4*blk + i of this wave, output channel j
+    if (jb < 3) {
         const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
-        const size_t o = (((size_t)b * p.H + y) * p.W + x) * 3;
+        const float bias = p.bias[jb], mj = mean[jb], sj = sd[jb];
+        const int blk = lane >> 2;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float t = acc[c] + p.bias[c];
-            if (p.out_pre) p.out_pre[o + c] = t;
-            float im = t * sd[c] + mean[c];
-            im = fminf(fmaxf(im, 0.f), 1.f) * 255.f;
-            p.out_img[o + 2 - c] = im;   // RGB -> BGR
+        for (int i = 0; i < 4; ++i) {
+            const int pix = 4 * blk + i;
+            const int y = y0 + 4 * wave + (pix >> 4), x = x0 + (pix & 15);
+            if (y < p.H && x < p.W) {
+                const size_t o = (((size_t)b * p.H + y) * p.W + x) * 3;
+                const float t = r[i] + bias;
+                if (p.out_pre) p.out_pre[o + jb] = t;
+                float im = t * sj + mj;
+                im = fminf(fmaxf(im, 0.f), 1.f) * 255.f;
+                p.out_img[o + 2 - jb] = im;   // RGB -> BGR
+            }
         }
     }
 }
