@@ -374,6 +374,7 @@ int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
                        (const float*)wd.bias, fd.raw, fd.bias, 512 * 9);
     HIPCHK(hipGetLastError());
     RCHK(pack(h, fd));
+    RCHK(pack_wino(h, fd));          // 512->32 is one Winograd cout slab
     hipLaunchKernelGGL(fold_up_k, dim3((512 * 32 * 9 + 255) / 256), dim3(256), 0, h->stream, F2, (const float*)wu.raw, fu.raw, 512);
     HIPCHK(hipGetLastError());
     RCHK(pack(h, fu));
