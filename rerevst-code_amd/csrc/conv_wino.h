@@ -92,12 +92,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
         w_tile = p.wpk + (size_t)n_tile * nchunks * (16 * 32 * 16);
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
+            // LDS pixel slot P: even halo columns first, then odd ones (162 slots each), row-major inside;
+            // stored piece qq holds channels 4*(qq ^ ((hx>>1)&3)).. : conflict-free for the stride-2 patch reads
             const int e = it * 256 + tid;
-            int pp = e >> 2;
+            int P = e >> 2;
             const int qq = e & 3;
-            if (pp >= 324) pp = 0;
-            const int hy = pp / 18, hx = pp - hy * 18;
-            asrc[it] = (((y0 + hy) * (p.Wi + 2) + (x0 + hx)) * p.Cin + 4 * (qq ^ ((pp >> 2) & 3))) * 4;
+            if (P >= 324) P = 0;
+            const int half = P >= 162, rem = P - half * 162;
+            const int hy = rem / 9, hx = 2 * (rem - hy * 9) + half;
+            asrc[it] = (((y0 + hy) * (p.Wi + 2) + (x0 + hx)) * p.Cin + 4 * (qq ^ ((hx >> 1) & 3))) * 4;
         }
     };
     auto stage_u = [&](int chunk) {
@@ -129,18 +132,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
         }
     };
 
-    // LDS byte addresses: this lane's 4x4 raw patch (pixel pp, 16-byte piece q, XOR swizzle), relative
-    // to the raw buffer; and its U fragment (row = pos*32 + nb*16 + t, (row>>2)&3 == (t>>2)&3)
+    // LDS byte addresses: this lane's 4x4 raw patch (slot P, 16-byte piece q, XOR swizzle), relative to
+    // the raw buffer; and its U fragment (row = pos*32 + nb*16 + t, (row>>2)&3 == (t>>2)&3)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     unsigned offD[16];   // index dx*4 + dy
 #pragma unroll
     for (int dx = 0; dx < 4; ++dx)
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) {
-            const int pp = (4 * wave + 2 * tr + dy) * 18 + 2 * tc + dx;
-            offD[dx * 4 + dy] = lds0 + pp * 64 + ((q ^ ((pp >> 2) & 3)) << 4);
+            const int hy = 4 * wave + 2 * tr + dy, hx = 2 * tc + dx;
+            const int P = (hx & 1) * 162 + hy * 9 + (hx >> 1);
+            offD[dx * 4 + dy] = lds0 + P * 64 + ((q ^ ((hx >> 1) & 3)) << 4);
         }
-    const unsigned offU = lds0 + 2 * WINO_RAW_BYTES + t * 64 + ((q ^ ((t >> 2) & 3)) << 4);
+    const unsigned offU = lds0 + 2 * WINO_RAW_BYTES + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);
 
     f32x4 acc[16][2];
     f32x4 va[16], vb[16];   // transformed input B^T d B of the current / next chunk (ping-pong)
@@ -365,7 +369,7 @@ __global__ void pack_wino_k(const float* __restrict__ w, float* __restrict__ dst
         const int chunk = r % nchunks; r /= nchunks;
         const int n_tile = (int)r;
         const int e = cl & 3, qs = cl >> 2;
-        const int qq = (CH == 16) ? (qs ^ ((j >> 2) & 3)) : qs;
+        const int qq = qs ^ ((0 - (j >> 2)) & 3);     // XOR mask (0,3,2,1)[(j>>2)&3]: conflict-free ds_read_b128 of a 16-row fragment
         const int co = n_tile * 32 + j, ci = chunk * CH + qq * 4 + e;
         const float* g = w + ((size_t)co * Cin + ci) * 9;
         const int pr = pos >> 2, pc = pos & 3;
