@@ -99,6 +99,11 @@ int rrv_transfer_batch(rrv_handle h, const uint8_t* frames_bgr, int B, int H, in
 int rrv_transfer_blend(rrv_handle h, const uint8_t* frame_bgr, int H, int W, const float* style_weight, int n_styles,
                        float* out_bgr);
 
+/* Stylization(checkpoint, cuda, use_Global=False).transfer (test/framework.py:69-72,106-118 with
+ * test/style_network_frame.py): per-frame InstanceNorm statistics (:39-43) and per-frame filter
+ * prediction (:53-62,97-105); needs only rrv_prepare_style (style 0).  Host buffers. */
+int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* out_bgr);
+
 /* Debug/parity taps: pre-clamp network output (normalised RGB, NHWC [H][W][3]) of the last
  * transfer, copied to host. */
 int rrv_get_preclamp(rrv_handle h, float* out, int H, int W);

@@ -270,13 +270,74 @@ class Decoder:
         return conv3x3(h, self._w("slice1.weight"), self._w("slice1.bias"))
 
 
+def inorm_frame(x, eps=F32(1e-8)):
+    """InstanceNorm.forward of the frame-mode network (test/style_network_frame.py:39-43): per-image,
+    per-channel over (H,W), biased, rsqrt; no saved state, no clamp."""
+    m = x.mean(axis=(1, 2), keepdims=True, dtype=F32)
+    xc = x - m
+    r = (F32(1) / np.sqrt((xc * xc).mean(axis=(1, 2), keepdims=True, dtype=F32) + eps)).astype(F32)
+    return xc * r
+
+
+class FrameDecoder:
+    """Decoder of test/style_network_frame.py (use_Global=False): per-frame statistics and per-frame
+    filter prediction; same weights / state_dict keys as the global model."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def _w(self, k):
+        return self.net.w["Decoder." + k]
+
+    def _predict(self, name, content, style):
+        """FilterPredictor.forward (style_network_frame.py:53-62)."""
+        p = name + "."
+        c = conv3x3(content, self._w(p + "down_sample.0.weight"), self._w(p + "down_sample.0.bias"))
+        c = c.reshape(-1, c.shape[-1]).mean(axis=0, dtype=F32)
+        s = conv3x3(style, self._w(p + "down_sample.0.weight"), self._w(p + "down_sample.0.bias"))
+        s = s.reshape(-1, s.shape[-1]).mean(axis=0, dtype=F32)
+        f = self._w(p + "FC.weight") @ np.concatenate([c, s]).astype(F32) + self._w(p + "FC.bias")
+        return f.reshape(32, 32).astype(F32)
+
+    def _kernel_filter(self, fname, content, style):
+        """KernelFilter.forward (style_network_frame.py:97-105)."""
+        p = fname + "."
+        d = conv3x3(content, self._w(p + "down_sample.0.weight"), self._w(p + "down_sample.0.bias"))
+        d = lrelu(apply_filter(d, self._predict(fname + ".F1", content, style)))
+        d = apply_filter(d, self._predict(fname + ".F2", content, style))
+        return content + conv3x3(d, self._w(p + "upsample.0.weight"), self._w(p + "upsample.0.bias"))
+
+    def _resblock(self, blk, x):
+        """ResidualBlock.forward (style_network_frame.py ResidualBlock: one stateless norm used twice)."""
+        x = upsample2(x)
+        xs = conv1x1(x, self._w(blk + ".conv_shortcut.weight"))
+        h = inorm_frame(lrelu(conv3x3(x, self._w(blk + ".conv1.weight"), self._w(blk + ".conv1.bias"))))
+        h = inorm_frame(lrelu(conv3x3(h, self._w(blk + ".conv2.weight"), self._w(blk + ".conv2.bias"))))
+        return xs + h
+
+    def forward(self, x, F_style):
+        """Decoder.forward / AdaIN_filter / AdaIN (style_network_frame.py:313-358)."""
+        m4, s4 = F_style["relu4_1"]
+        h = inorm_frame(x)
+        sn = ((F_style["map"] - m4) / s4).astype(F32)
+        for f in ("Filter1", "Filter2", "Filter3"):
+            h = self._kernel_filter(f, h, sn)
+        h = h * s4 + m4                      # no second normalisation here (unlike the global model)
+        h = self._resblock("slice4", h)
+        h = inorm_frame(h) * F_style["relu3_1"][1] + F_style["relu3_1"][0]
+        h = self._resblock("slice3", h)
+        h = inorm_frame(h) * F_style["relu2_1"][1] + F_style["relu2_1"][0]
+        h = self._resblock("slice2", h)
+        h = inorm_frame(h) * F_style["relu1_1"][1] + F_style["relu1_1"][0]
+        return conv3x3(h, self._w("slice1.weight"), self._w("slice1.bias"))
+
+
 class Stylization:
     """Mirror of the reference ``Stylization`` call surface (test/framework.py:56-118),
     constructed from a weight dict instead of a checkpoint path."""
 
     def __init__(self, weights, use_Global=True):
-        if not use_Global:
-            raise NotImplementedError("frame mode (style_network_frame.py) is out of scope (SURVEY §8f)")
+        self.use_Global = use_Global
         self.net = Net(weights)
         self.dec = Decoder(self.net)
         self.F_style = None
@@ -302,7 +363,10 @@ class Stylization:
     # test/framework.py:106-118 -> TransformerNet.forward :499-501
     def transfer(self, frame, return_preclamp=False):
         f = self.net.encoder(rgb2gray(image_to_tensor(frame)))
-        y = self.dec.run(f, self.F_style, compute=False)
+        if self.use_Global:
+            y = self.dec.run(f, self.F_style, compute=False)
+        else:
+            y = FrameDecoder(self.net).forward(f, self.F_style)
         if return_preclamp:
             return y
         return tensor_to_image(y)

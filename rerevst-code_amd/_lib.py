@@ -33,6 +33,7 @@ SYMBOLS = {
     "rrv_transfer_blend_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "rrv_transfer_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rrv_transfer_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "rrv_transfer_frame_mode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rrv_get_preclamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_sync": (C.c_int, [C.c_void_p]),
     "rrv_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),

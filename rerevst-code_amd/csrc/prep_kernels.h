@@ -234,6 +234,13 @@ __global__ void pointwise_k(const PointP p) {
     }
 }
 
+// identity saved-statistics entry (mean 0, rstd 1, lo -inf, hi +inf): frame mode has no second
+// normalisation after the filters (test/style_network_frame.py AdaIN_filter: results*std+mean)
+__global__ void identity_norm_k(float* __restrict__ n, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { n[c] = 0.f; n[C + c] = 1.f; n[2 * C + c] = -3.0e38f; n[3 * C + c] = 3.0e38f; }
+}
+
 // blended state for multi-style interpolation: out = sum_s w[s] * state_s
 // ("Multi-style Interpolation/style_network.py":41-45,137-138,354-356)
 struct BlendP { const float* st[8]; float w[8]; int n; float* out; int count; };

@@ -517,7 +517,9 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
 }
 
 // ---- preparation: Decoder.compute for one style ---------------------------------------------
-int compute_style(rrv_handle h, int sid, const Tens& content) {
+// frame_mode: the per-frame-statistics network of test/style_network_frame.py (use_Global=False) is this
+// same pass with B = 1 and no normalisation between the filters and the first AdaIN affine.
+int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = false) {
     StyleState& S = h->styles[sid];
     float* st = S.blob;
     const int B = content.B, hh = content.H, ww = content.W;
@@ -561,9 +563,14 @@ int compute_style(rrv_handle h, int sid, const Tens& content) {
             Tens* t = cur; cur = other; other = t;
         }
         h->active_src = -1;   // folded weights now belong to this style's blob; re-activate below
-        // AdaIN_compute(1) (:428)
-        RCHK(chan_stats(h, *cur, 1, st + SL.norm[N_DEC1]));
-        RCHK(pointwise(h, *cur, *cur, st + SL.norm[N_DEC1], st + SL.norm[N_DEC1] + 512, false, nullptr, 0, st + SL.sty[3], st + SL.sty[3] + 512));
+        if (frame_mode) {   // style_network_frame.py AdaIN_filter: results * style_std + style_mean
+            hipLaunchKernelGGL(identity_norm_k, dim3(2), dim3(256), 0, h->stream, st + SL.norm[N_DEC1], 512);
+            HIPCHK(hipGetLastError());
+            RCHK(pointwise(h, *cur, *cur, nullptr, nullptr, false, nullptr, 0, st + SL.sty[3], st + SL.sty[3] + 512));
+        } else {            // AdaIN_compute(1) (style_network_global.py:428)
+            RCHK(chan_stats(h, *cur, 1, st + SL.norm[N_DEC1]));
+            RCHK(pointwise(h, *cur, *cur, st + SL.norm[N_DEC1], st + SL.norm[N_DEC1] + 512, false, nullptr, 0, st + SL.sty[3], st + SL.sty[3] + 512));
+        }
         struct Blk { const char* name; int cout, n1, n2, nada, sty; };
         const Blk blks[3] = {{"slice4", 256, N_S4N1, N_S4N2, N_DEC2, 2}, {"slice3", 128, N_S3N1, N_S3N2, N_DEC3, 1}, {"slice2", 64, N_S2N1, N_S2N2, N_DEC4, 0}};
         Tens in = *cur;   // shallow view
@@ -913,6 +920,40 @@ int rrv_transfer_batch(rrv_handle h, const uint8_t* frames, int B, int H, int W,
 int rrv_transfer_blend(rrv_handle h, const uint8_t* frame, int H, int W, const float* wts, int ns, float* out) {
     if (!wts) return RRV_E_ARG;
     return host_roundtrip(h, frame, 1, H, W, out, wts, ns);
+}
+
+// Stylization(use_Global=False).transfer (test/framework.py:106-118 with test/style_network_frame.py):
+// per-frame InstanceNorm statistics and per-frame filter prediction.  Implemented as the preparation
+// pass on this one frame (B = 1, frame_mode) followed by the saved-state forward with that state.
+int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame, int H, int W, float* out) {
+    if (!h || !frame || !out) return RRV_E_ARG;
+    if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
+    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
+    HIPCHK(hipSetDevice(h->dev));
+    StyleState& S = h->styles[0];
+    if (!S.prepared) return fail(h, RRV_E_STATE, "prepare_style has not been called");
+    RCHK(sync_all(h));
+    const size_t n = (size_t)H * W * 3;
+    RCHK(ensure_u8(h, n));
+    HIPCHK(hipMemcpyAsync(h->d_u8, frame, n, hipMemcpyHostToDevice, h->stream));
+    RCHK(enc_plan(h, h->enc_add, 1, H, W));
+    RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr));
+    Tens content = h->enc_add.c41;          // view: [1, H/8, W/8, 512] raw relu4_1 feature
+    RCHK(compute_style(h, 0, content, true));
+    h->active_src = -1;
+    RCHK(activate_state(h, 0));
+    if (h->d_outf_cap < n) {
+        if (h->d_outf) (void)hipFree(h->d_outf);
+        h->d_outf = nullptr; h->d_outf_cap = 0;
+        HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
+        h->d_outf_cap = n;
+    }
+    h->next_slot = 0;
+    RCHK(transfer_device(h, h->d_u8, 1, H, W, h->d_outf));
+    h->next_slot = 0;
+    HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
+    HIPCHK(hipStreamSynchronize(h->streams[0]));
+    return RRV_OK;
 }
 
 int rrv_get_preclamp(rrv_handle h, float* out, int H, int W) {

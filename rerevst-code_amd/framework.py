@@ -34,8 +34,7 @@ class Stylization():
     def __init__(self, checkpoint, cuda=True, use_Global=True, device=None, style_num=1):
         if not cuda:
             raise RRVError("this implementation only runs on an MI355X GPU (cuda=False has no CPU fallback)")
-        if not use_Global:
-            raise NotImplementedError("use_Global=False (style_network_frame.py) is not built yet (SURVEY.md §8(f) rank 3)")
+        self.use_Global = bool(use_Global)   # False: per-frame statistics model of test/style_network_frame.py
         self._lib = _lib.load()
         if device is None:
             import os
@@ -76,14 +75,21 @@ class Stylization():
             pass
 
     # ===== Sequence-Level Global Feature Sharing (test/framework.py:82-95) =====
+    def _global_only(self, what):
+        if not self.use_Global:   # the reference's frame-mode TransformerNet has no add/compute/clean either
+            raise RRVError("%s() belongs to Sequence-Level Global Feature Sharing (use_Global=True)" % what)
+
     def add(self, patch):
+        self._global_only("add")
         a = _u8_image(patch, "patch")
         self._chk(self._lib.rrv_add(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]))
 
     def compute(self):
+        self._global_only("compute")
         self._chk(self._lib.rrv_compute(self._h))
 
     def clean(self):
+        self._global_only("clean")
         self._chk(self._lib.rrv_clean(self._h))
 
     # ===== Style Transfer (test/framework.py:99-118) =====
@@ -102,6 +108,9 @@ class Stylization():
         a = _u8_image(frame, "frame")
         H, W = a.shape[:2]
         out = np.empty((H, W, 3), dtype=np.float32)
+        if not self.use_Global:
+            self._chk(self._lib.rrv_transfer_frame_mode(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p)))
+            return out
         if style_weight is None:
             self._chk(self._lib.rrv_transfer(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p)))
             return out

@@ -184,6 +184,34 @@ def run_multistyle(name, weights):
              pre_crop=pre[64:128, 64:112].astype(np.float32), out_crop=out[64:128, 64:112].astype(np.float32))
 
 
+def run_frame_mode(name, weights):
+    """use_Global=False (test/style_network_frame.py): per-frame statistics, no saved state."""
+    fw, G = R.import_reference("test", "framework", "style_network_frame")
+    s = fw.Stylization.__new__(fw.Stylization)
+    s.device = torch.device("cpu")
+    s.model = G.TransformerNet()
+    new = {}
+    for k, v in s.model.state_dict().items():
+        new[k] = torch.from_numpy(weights[k].copy()) if k in weights else torch.zeros_like(v)
+        assert k in weights or k.startswith("Vgg19."), k
+    s.model.load_state_dict(new, strict=True)
+    style = pkg.synth_style(64, 64, kind="smooth", seed=7)
+    frame = O.reflect_pad(pkg.synth_frame(2, 64, 48, kind="smooth"), 192, 192)
+    s.prepare_style(style)
+    taps = {}
+    hk = s.model.Decoder.slice1.register_forward_hook(lambda m, i, o: taps.__setitem__("pre", nhwc(o)))
+    out = s.transfer(frame.copy())
+    hk.remove()
+    pre = taps["pre"][0]
+    o = O.Stylization(weights, use_Global=False)
+    o.prepare_style(style)
+    opre = o.transfer(frame, return_preclamp=True)[0]
+    print("[%s] pre-clamp max|d| %.3e (std %.3f) | image max|d| %.4f" % (name, np.abs(opre - pre).max(), pre.std(),
+                                                                      np.abs(o.transfer(frame) - out).max()))
+    np.savez(os.path.join(HERE, name + ".npz"), pre_crop=pre[64:128, 64:112].astype(np.float32),
+             out_crop=out[64:128, 64:112].astype(np.float32))
+
+
 def main():
     w = pkg.synthetic_weights(0)
     # A: 3 sampled frames (Q1,Q3,Q4), transfer of a NON-sampled frame, full padded output
@@ -191,6 +219,7 @@ def main():
     # B: frame sides not multiples of 8 (pool floors in add), P=256x192, cropped output only
     run_case("global_b", w, (72, 56), (90, 50), 3, [0, 2], 1, crop_only=True)
     run_multistyle("multistyle_s2", w)
+    run_frame_mode("frame_mode", w)
 
 
 if __name__ == "__main__":

@@ -168,3 +168,22 @@ def test_pipelined_device_calls_match_serial(pkg, oracle, weights):
         s.sync()
         np.testing.assert_array_equal(d_out.cpu().numpy(), serial)
     s.close()
+
+
+def test_frame_mode_matches_reference(pkg, weights, oracle):
+    """Stylization(use_Global=False): rrv_transfer_frame_mode against the frame-mode reference golden."""
+    g = load_golden("frame_mode")
+    s = pkg.Stylization(weights, cuda=True, use_Global=False)
+    s.prepare_style(pkg.synth_style(64, 64, kind="smooth", seed=7))
+    frame = oracle.reflect_pad(pkg.synth_frame(2, 64, 48, kind="smooth"), 192, 192)
+    out = s.transfer(frame)
+    assert_pre_close(s.preclamp(192, 192)[64:128, 64:112], g["pre_crop"])
+    assert np.abs(out[64:128, 64:112] - g["out_crop"]).max() <= IMG_ATOL
+    with pytest.raises(pkg.RRVError):
+        s.add(frame)
+    # a second, different frame gets its own statistics
+    f2 = oracle.reflect_pad(pkg.synth_frame(5, 64, 48, kind="smooth"), 192, 192)
+    o = oracle.Stylization(weights, use_Global=False)
+    o.prepare_style(pkg.synth_style(64, 64, kind="smooth", seed=7))
+    assert np.abs(s.transfer(f2) - o.transfer(f2)).max() <= IMG_ATOL
+    s.close()

@@ -92,3 +92,13 @@ def test_multistyle_blend_matches_reference(oracle, pkg, weights):
     assert_pre_close(pre, g["pre_crop"])
     assert np.abs(o.transfer(feats[1], wts)[64:128, 64:112] - g["out_crop"]).max() <= IMG_ATOL
     assert oracle.sample_indices_multistyle(33) == [0, 16, 32, 32]
+
+
+def test_frame_mode_matches_reference(oracle, pkg, weights):
+    """use_Global=False model (test/style_network_frame.py): per-frame statistics, no saved state."""
+    g = load_golden("frame_mode")
+    o = oracle.Stylization(weights, use_Global=False)
+    o.prepare_style(pkg.synth_style(64, 64, kind="smooth", seed=7))
+    frame = oracle.reflect_pad(pkg.synth_frame(2, 64, 48, kind="smooth"), 192, 192)
+    assert_pre_close(o.transfer(frame, return_preclamp=True)[0][64:128, 64:112], g["pre_crop"])
+    assert np.abs(o.transfer(frame)[64:128, 64:112] - g["out_crop"]).max() <= IMG_ATOL
