@@ -5,7 +5,7 @@
 // down/up convs :181-187; ResidualBlock conv1/conv2/conv_shortcut :103-105) together with
 // the pointwise ops the reference runs as separate eager kernels after them: bias,
 // ReLU / LeakyReLU(0.2), MaxPool2d(2) (vgg cfg), F.interpolate(nearest, x2) in front of
-// the conv (:113), saved-statistics InstanceNorm.forward (:43-57), the residual adds
+// the conv (:113, conv_ups2_k), saved-statistics InstanceNorm.forward (:43-57), the residual adds
 // (:122, :217) and the AdaIN affine (:357-364).
 //
 // Data layout (HBM): activations are NHWC fp32 with a one-pixel ZERO ring:
@@ -46,7 +46,7 @@ enum {
 };
 
 struct ConvP {
-    const float* in;   // input tensor (ring layout); dims Hi,Wi (half of H,W when UPS)
+    const float* in;   // input tensor (ring layout); dims Hi,Wi (half of H,W for conv_ups2_k)
     int Hi, Wi, Cin;
     float* out;        // output tensor (ring layout); dims H,W (H/2,W/2 when E_POOL)
     int H, W, Cout;    // convolution resolution and output channels
@@ -88,13 +88,13 @@ __device__ __forceinline__ void bufld16(const void* base, char* lds_wave_base, i
 // 2 = no barriers, 4 = no stores); the library always instantiates ABL = 0.
 // MSUB overrides the number of M-subtiles per wave (tile rows = WAVES_M * MSUB * 2); LD selects the
 // LDS-DMA flavour (0: global_load_lds, 1: buffer_load ... lds with a wave-uniform descriptor).
-template <int BN, int TAPS, bool UPS, int EPI, int ABL = 0, int MSUB = 0, int LD = 1>
+template <int BN, int TAPS, int EPI, int ABL = 0, int MSUB = 0, int LD = 1>
 __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
     using WC = WaveCfg<BN>;
     constexpr int WM_SUB = MSUB ? MSUB : WC::WM_SUB;
     constexpr int TROWS = WC::WAVES_M * WM_SUB * 2;             // output tile rows (x 16 cols)
-    constexpr int HWD = (TAPS == 1) ? 16 : (UPS ? 10 : 18);   // halo tile width  (pixels)
-    constexpr int HHT = (TAPS == 1) ? TROWS : (UPS ? TROWS / 2 + 2 : TROWS + 2);   // halo tile height
+    constexpr int HWD = (TAPS == 1) ? 16 : 18;                 // halo tile width  (pixels)
+    constexpr int HHT = (TAPS == 1) ? TROWS : TROWS + 2;       // halo tile height
     constexpr int NPIX = HHT * HWD;
     constexpr int A_ITERS = (NPIX * 4 + 255) / 256;
     constexpr int A_BYTES = A_ITERS * 256 * 16;
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
 
     // ---- per-lane global source offsets of the A (halo) pieces; chunk base added later
     const float* in_b = p.in + (size_t)(p.in_bstride0 ? b : 0) * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
-    const int ys = (TAPS == 1) ? y0 : (UPS ? (y0 >> 1) - 1 : y0 - 1);
-    const int xs = (TAPS == 1) ? x0 : (UPS ? (x0 >> 1) - 1 : x0 - 1);
+    const int ys = (TAPS == 1) ? y0 : y0 - 1;
+    const int xs = (TAPS == 1) ? x0 : x0 - 1;
     int asrc[A_ITERS];
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
@@ -201,8 +201,6 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
                 int pp;
                 if (TAPS == 1)
                     pp = (2 * msg + r_) * HWD + c_;
-                else if (UPS)
-                    pp = ((2 * msg + r_ + ky + 1) >> 1) * HWD + ((c_ + kx + 1) >> 1);
                 else
                     pp = (2 * msg + r_ + ky) * HWD + c_ + kx;
                 offA[ms] = pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);   // g=0; g=1 flips bit 5

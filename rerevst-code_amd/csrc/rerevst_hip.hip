@@ -6,7 +6,6 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -102,7 +101,6 @@ struct rrv_ctx {
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
     float* d_outf = nullptr; size_t d_outf_cap = 0;
     int n_cus = 256;
-    bool use_wino = true;                      // Winograd F(2x2,3x3) for the 3x3 layers that have a transformed pack
     bool profiling = false;
     std::vector<ProfEntry> prof;
 };
@@ -169,26 +167,21 @@ struct ConvCall {
     int B = 1;
 };
 
-template <int BN, int TAPS, bool UPS, int EPI>
+template <int BN, int TAPS, int EPI>
 void conv_launch(const ConvP& p, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, UPS, EPI>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, EPI>), grid, dim3(256), 0, s, p);
 }
 
 typedef void (*ConvFn)(const ConvP&, dim3, hipStream_t);
 struct ConvKey { int BN, TAPS, UPS, EPI; ConvFn fn; const char* name; };
-#define CK(BN, TAPS, UPS, EPI) {BN, TAPS, UPS, EPI, &conv_launch<BN, TAPS, UPS, EPI>, "conv_mfma<" #BN "," #TAPS "," #UPS "," #EPI ">"}
+#define CK(BN, TAPS, UPS, EPI) {BN, TAPS, UPS, EPI, &conv_launch<BN, TAPS, EPI>, "conv_mfma<" #BN "," #TAPS "," #EPI ">"}
 const ConvKey CONV_TABLE[] = {
-    // encoder
-    CK(64, 9, 0, E_RELU | E_POOL), CK(128, 9, 0, E_RELU), CK(128, 9, 0, E_RELU | E_POOL),
-    CK(128, 9, 0, E_RELU | E_NORM1), CK(64, 9, 0, E_RELU),
-    // KernelFilter (folded dynamic filters)
-    CK(32, 9, 0, E_LRELU), CK(128, 9, 0, E_RES), CK(128, 9, 0, E_RES | E_NORM2),
-    // residual blocks, per-frame
+    // 1x1 shortcuts of the residual blocks (evaluated before the upsample)
     CK(128, 1, 0, 0), CK(64, 1, 0, 0),
-    CK(128, 9, 0, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), CK(64, 9, 0, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2),
-    // preparation pass (raw outputs, statistics taken afterwards)
+    // KernelFilter 32->512 convs with the folded dynamic filter (+ residual, + AdaIN after Filter3)
+    CK(128, 9, 0, E_RES), CK(128, 9, 0, E_RES | E_NORM2),
+    // preparation pass: FilterPredictor 512->32 convs and the 32->512 conv of frame 0 (raw outputs)
     CK(32, 9, 0, 0), CK(128, 9, 0, 0),
-    CK(128, 9, 0, E_LRELU), CK(64, 9, 0, E_LRELU),
 };
 
 template <int BN, int EPI>
@@ -216,7 +209,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     const ConvW& w = *c.w;
     const ConvKey* k = nullptr;
     bool wino = false;
-    if (!c.ups && w.pk_wino && h->use_wino) {
+    if (!c.ups && w.pk_wino) {      // every 3x3 layer with a Winograd pack runs conv_wino_k
         for (const ConvKey& e : WINO_TABLE)
             if (e.EPI == c.epi) { k = &e; wino = true; break; }
     }
@@ -630,7 +623,6 @@ int rrv_create(int device, rrv_handle* out) {
         return RRV_E_HIP;
     }
     h->stream = h->streams[0];
-    if (const char* e = getenv("RRV_WINO")) h->use_wino = (e[0] != '0');
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;

@@ -15,10 +15,10 @@ float run(ConvP p, int iters) {
     dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / BN);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, false, EPI, ABL, MSUB, LD>), grid, dim3(256), 0, 0, p);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, EPI, ABL, MSUB, LD>), grid, dim3(256), 0, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, false, EPI, ABL, MSUB, LD>), grid, dim3(256), 0, 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_mfma_k<BN, TAPS, EPI, ABL, MSUB, LD>), grid, dim3(256), 0, 0, p);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -80,7 +80,7 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
         long long* dbg; CK(hipMalloc(&dbg, (size_t)nw * 4 * 8));
         ConvP q = p; q.n1 = (const float*)dbg;
         dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / BN);
-        hipLaunchKernelGGL((conv_mfma_k<BN, 9, false, E_RELU, 16>), grid, dim3(256), 0, 0, q);
+        hipLaunchKernelGGL((conv_mfma_k<BN, 9, E_RELU, 16>), grid, dim3(256), 0, 0, q);
         CK(hipDeviceSynchronize());
         std::vector<long long> h((size_t)nw * 4);
         CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
