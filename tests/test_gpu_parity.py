@@ -187,3 +187,17 @@ def test_frame_mode_matches_reference(pkg, weights, oracle):
     o.prepare_style(pkg.synth_style(64, 64, kind="smooth", seed=7))
     assert np.abs(s.transfer(f2) - o.transfer(f2)).max() <= IMG_ATOL
     s.close()
+
+
+def test_white_noise_frames_vs_oracle(pkg, oracle, weights):
+    """The bench's synthetic video is white noise; check the same content class for parity."""
+    style = pkg.synth_style(64, 64, kind="noise", seed=7)
+    sampled = [pkg.synth_frame(i, 96, 96, kind="noise") for i in (0, 8)]
+    s, o = _prep_pair(pkg, oracle, weights, style, sampled)
+    assert_state_close(s.get_state(), o.get_state())
+    o.set_state(s.get_state())
+    frame = oracle.reflect_pad(pkg.synth_frame(3, 96, 96, kind="noise"), 256, 256)
+    out = s.transfer(frame)
+    assert_pre_close(s.preclamp(256, 256), o.transfer(frame, return_preclamp=True)[0])
+    assert np.abs(out - o.transfer(frame)).max() <= IMG_ATOL
+    s.close()
