@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + 2 * B_BYTES];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: LDS-DMA bases in SGPRs
+    const int lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wave_m = wave % WC::WAVES_M, wave_n = wave / WC::WAVES_M;
 
     int bx = blockIdx.x;
@@ -336,7 +337,8 @@ __global__ __launch_bounds__(256) void conv_ups2_k(const ConvP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + 2 * B_BYTES];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: LDS-DMA bases in SGPRs
+    const int lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int px = wave % 2, wave_n = wave / 2;
 
     int bx = blockIdx.x;

@@ -37,9 +37,11 @@
 
 // LDS reads of the hand-pipelined main loop: issued early by inline asm, released by counted
 // s_waitcnt lgkmcnt(N) (LDS returns in order), so the single wave per SIMD never parks on LDS latency.
-__device__ __forceinline__ f32x4 lds_rd128(unsigned addr) {
+template <int IMM>
+__device__ __forceinline__ f32x4 lds_rd128(unsigned addr) {     // LDS byte address = addr + IMM (16-bit immediate)
+    static_assert(IMM >= 0 && IMM < 65536, "ds_read offset is a 16-bit unsigned immediate");
     f32x4 r;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(IMM));
     return r;
 }
 template <int N>
@@ -69,7 +71,8 @@ template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, t = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
+    const int lane = tid & 63, t = lane & 15, q = lane >> 4;
     const int tr = t >> 3, tc = t & 7;
     const int nchunks = p.Cin >> 4;      // even (Cin >= 64)
     const int n_ntiles = p.Cout >> 5;
@@ -145,32 +148,36 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
             offD[dx * 4 + dy] = lds0 + P * 64 + ((q ^ ((hx >> 1) & 3)) << 4);
         }
     const unsigned offU = lds0 + 2 * WINO_RAW_BYTES + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);
+    const unsigned offU1 = offU + WINO_U_BYTES;
 
     f32x4 acc[16][2];
     f32x4 va[16], vb[16];   // transformed input B^T d B of the current / next chunk (ping-pong)
 
     // One chunk: MFMAs of chunk c with V(c) = vcur, while the raw patch of chunk c+1 is read and
     // transformed into vnext.  Issue order per iteration i: U(i+2) x2, then (i<8) patch pieces 2i, 2i+1.
-    auto chunk_body = [&](int c, f32x4 (&vcur)[16], f32x4 (&vnext)[16]) {
+    // c is even in the first body of the unrolled chunk loop and odd in the second (PAR = c & 1), so the
+    // buffer selection folds into the 16-bit immediate of every ds_read: no address arithmetic in the loop
+    auto chunk_body = [&](int c, auto par_c, f32x4 (&vcur)[16], f32x4 (&vnext)[16]) {
+        constexpr int PAR = decltype(par_c)::value;
         if (!(ABL & 1)) {
             if (c + 1 < nchunks) stage_u(c + 1);          // U buffer (c+1)&1: last read in iteration c-1
             if (c + 2 < nchunks) stage_raw(c + 2);        // raw buffer c&1: its patch was read in iteration c-1
         }
-        const unsigned ub = offU + (c & 1) * WINO_U_BYTES;
-        const unsigned rb = ((c + 1) & 1) * WINO_RAW_BYTES;
+        const unsigned ub = PAR ? offU1 : offU;
+        constexpr int RB = (1 - PAR) * WINO_RAW_BYTES;    // raw buffer (c+1)&1
         f32x4 u[4][2];       // U fragments in flight, slot = pos & 3
         f32x4 d[16];         // raw patch of the next chunk, index dx*4 + dy; becomes B^T d column by column
-        u[0][0] = lds_rd128(ub); u[0][1] = lds_rd128(ub + 1024);
-        u[1][0] = lds_rd128(ub + 2048); u[1][1] = lds_rd128(ub + 2048 + 1024);
+        u[0][0] = lds_rd128<0>(ub); u[0][1] = lds_rd128<1024>(ub);
+        u[1][0] = lds_rd128<2048>(ub); u[1][1] = lds_rd128<2048 + 1024>(ub);
         static_for([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if (i + 2 < 16) {
-                u[(i + 2) & 3][0] = lds_rd128(ub + (i + 2) * 2048);
-                u[(i + 2) & 3][1] = lds_rd128(ub + (i + 2) * 2048 + 1024);
+            if constexpr (i + 2 < 16) {
+                u[(i + 2) & 3][0] = lds_rd128<(i + 2) * 2048>(ub);
+                u[(i + 2) & 3][1] = lds_rd128<(i + 2) * 2048 + 1024>(ub);
             }
-            if (i < 8) {
-                d[2 * i] = lds_rd128(offD[2 * i] + rb);
-                d[2 * i + 1] = lds_rd128(offD[2 * i + 1] + rb);
+            if constexpr (i < 8) {
+                d[2 * i] = lds_rd128<RB>(offD[2 * i]);
+                d[2 * i + 1] = lds_rd128<RB>(offD[2 * i + 1]);
             }
             // U(i) is complete when at most wino_younger(i) younger reads are outstanding; in-order
             // return also completes every patch piece issued before U(i), i.e. pieces < 2(i-2)
@@ -241,9 +248,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
             }
         }
         for (int c = 0; c < nchunks; c += 2) {
-            chunk_body(c, va, vb);
+            chunk_body(c, std::integral_constant<int, 0>{}, va, vb);
             if (!(ABL & 2)) __syncthreads();      // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
-            chunk_body(c + 1, vb, va);
+            chunk_body(c + 1, std::integral_constant<int, 1>{}, vb, va);
             if (!(ABL & 2)) __syncthreads();
         }
         // every LDS buffer is free now: start the next work item's loads before this item's epilogue
