@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
         for (int it = 0; it < B_ITERS; ++it) {
             if (B_PIECES >= 256 || wave * 64 < B_PIECES) {
                 if (LD == 1)
-                    bufld16(w_tile, bdst + (it * 256 + wave * 64) * 16, tid * 16 + it * 4096, (chunk * TAPS + tap) * (BN * 64));
+                    bufld16(w_tile, bdst + (it * 256 + wave * 64) * 16, tid * 16, (chunk * TAPS + tap) * (BN * 64) + it * 4096);
                 else
                     glds16(wb + it * 1024, bdst + (it * 256 + wave * 64) * 16);
             }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void conv_ups2_k(const ConvP p) {
         char* bdst = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it)
-            bufld16(w_tile, bdst + (it * 256 + wave * 64) * 16, tid * 16 + it * 4096, ((chunk * 2 + py) * 4 + tap) * (2 * BN * 64));
+            bufld16(w_tile, bdst + (it * 256 + wave * 64) * 16, tid * 16, ((chunk * 2 + py) * 4 + tap) * (2 * BN * 64) + it * 4096);
         if (tap == 0) {
             char* adst = smem + (chunk & 1) * A_BYTES;
 #pragma unroll

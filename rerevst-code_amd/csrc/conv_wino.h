@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
     auto stage_u = [&](int chunk) {
         char* udst = smem + 2 * WINO_RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) bufld16(w_tile, udst + (it * 256 + wave * 64) * 16, tid * 16 + it * 4096, chunk * WINO_U_BYTES);
+        for (int it = 0; it < 8; ++it) bufld16(w_tile, udst + (it * 256 + wave * 64) * 16, tid * 16, chunk * WINO_U_BYTES + it * 4096);
     };
     auto stage_raw = [&](int chunk) {
         char* rdst = smem + (chunk & 1) * WINO_RAW_BYTES;
