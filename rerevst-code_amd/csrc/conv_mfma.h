@@ -60,6 +60,7 @@ struct ConvP {
     const float* n2;   // [4][Cout]
     const float* sty;  // [2][Cout]: style mean, style std
     int tiles_x, tiles_y;
+    int xcd_slabs;     // conv_wino_k: co-locate the cout slabs of a pixel tile on one XCD (see conv_wino.h)
 };
 
 template <int BN>

@@ -76,16 +76,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
     const int tr = t >> 3, tc = t & 7;
     const int nchunks = p.Cin >> 4;      // even (Cin >= 64)
     const int n_ntiles = p.Cout >> 5;
-    const int total = p.tiles_x * p.tiles_y * p.B * n_ntiles;
 
     // ---- per-tile state of the tile being LOADED (the persistent loop prefetches one tile ahead)
     int y0 = 0, x0 = 0, b = 0, n_tile = 0;
     const float* in_b = p.in;
     const float* w_tile = p.wpk;
     int asrc[6];
-    auto setup = [&](int tile) {
-        n_tile = tile % n_ntiles;          // the cout slabs of one pixel tile run side by side: its raw input stays in L2
-        int r = tile / n_ntiles;
+    // Work item of this workgroup in round r.  Workgroup w runs on XCD w % 8 (observed dispatch order; used
+    // for locality only).  p.xcd_slabs != 0: the S cout slabs of one pixel tile are given to workgroups of
+    // the SAME XCD in the same round, so the raw input tile is fetched from HBM once and then hits that XCD's
+    // L2 (otherwise every XCD owns one slab — its U stays L2-resident — and re-fetches every input tile).
+    const int n_pix = p.tiles_x * p.tiles_y * p.B;
+    auto setup = [&](int round) -> bool {
+        int pix;
+        const int G = gridDim.x, w = blockIdx.x;
+        if (p.xcd_slabs) {
+            const int PT = (G >> 3) / n_ntiles;            // pixel tiles per XCD per round
+            pix = (round * 8 + (w & 7)) * PT + (w >> 3) / n_ntiles;
+            n_tile = (w >> 3) % n_ntiles;
+        } else {
+            const int item = w + round * G;
+            n_tile = item % n_ntiles;
+            pix = item / n_ntiles;
+        }
+        if (pix >= n_pix) return false;
+        int r = pix;
         const int tx = r % p.tiles_x;
         r /= p.tiles_x;
         const int ty = r % p.tiles_y;
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
             const int hy = rem / 9, hx = 2 * (rem - hy * 9) + half;
             asrc[it] = (((y0 + hy) * (p.Wi + 2) + (x0 + hx)) * p.Cin + 4 * (qq ^ ((hx >> 1) & 3))) * 4;
         }
+        return true;
     };
     auto stage_u = [&](int chunk) {
         char* udst = smem + 2 * WINO_RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
@@ -212,15 +228,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
 
     // ---- persistent loop over (pixel tile, cout slab) work items; the next item's first tiles are in
     // flight while the current item's epilogue runs
-    int tile = blockIdx.x;
-    if (tile < total) {
-        setup(tile);
+    int round = 0;
+    bool have = setup(round);
+    if (have) {
         stage_raw(0);
         stage_u(0);
         stage_raw(1);
     }
     int par_ntile = -1;
-    while (tile < total) {
+    while (have) {
         const int e_y0 = y0, e_x0 = x0, e_b = b, e_ntile = n_tile;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -254,9 +270,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
             if (!(ABL & 2)) __syncthreads();
         }
         // every LDS buffer is free now: start the next work item's loads before this item's epilogue
-        tile += gridDim.x;
-        if (tile < total && !(ABL & 1)) {
-            setup(tile);
+        have = setup(++round);
+        if (have && !(ABL & 1)) {
             stage_raw(0);
             stage_u(0);
             stage_raw(1);

@@ -242,8 +242,11 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (c.ups || wino) { p.tiles_y = (c.H + 15) / 16; }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B * (c.ups ? 2 : 1)), (unsigned)(w.Cout / w.BN));
     if (wino) {   // persistent workgroups, one per CU, walking tiles_x*tiles_y*B*(Cout/32) work items
-        const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B * (w.Cout / 32));
+        const unsigned slabs = (unsigned)(w.Cout / 32);
+        const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B) * slabs;
         grid = dim3(items < (unsigned)h->n_cus ? items : (unsigned)h->n_cus, 1);
+        // slabs of one pixel tile on one XCD (workgroup w runs on XCD w % 8): the raw tile is fetched once per XCD group
+        p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
     }
     const double px = (double)c.B * c.H * c.W;
     // algorithmic FLOPs = the reference's direct convolution (taps multiply-adds per output);
