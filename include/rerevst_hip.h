@@ -99,6 +99,16 @@ int rrv_transfer_batch(rrv_handle h, const uint8_t* frames_bgr, int B, int H, in
 int rrv_transfer_blend(rrv_handle h, const uint8_t* frame_bgr, int H, int W, const float* style_weight, int n_styles,
                        float* out_bgr);
 
+/* Multi-style feature API ("Multi-style Interpolation/stylization.py"): generate_content_features :87-92
+ * (encode a frame once; the reference caches the tensor on disk, test.py:87-101 — here it stays in HBM and
+ * an integer id is returned), add_patch :66-67 (sample a cached feature for the statistics pass; then
+ * rrv_compute == compute_norm :81-83), transfer(feature, style_weight) :94-100 (decoder only, blended state).
+ * rrv_release_features frees the cache. */
+int rrv_generate_content_features(rrv_handle h, const uint8_t* frame_bgr, int H, int W, int* feature_id);
+int rrv_add_patch(rrv_handle h, int feature_id);
+int rrv_transfer_features(rrv_handle h, int feature_id, const float* style_weight, int n_styles, float* out_bgr);
+int rrv_release_features(rrv_handle h);
+
 /* Stylization(checkpoint, cuda, use_Global=False).transfer (test/framework.py:69-72,106-118 with
  * test/style_network_frame.py): per-frame InstanceNorm statistics (:39-43) and per-frame filter
  * prediction (:53-62,97-105); needs only rrv_prepare_style (style 0).  Host buffers. */

@@ -208,6 +208,7 @@ struct PointP {
     const float* res; int res_mode;          // 0 none, 1 same-res image 0 broadcast, 2 half-res per batch
     int Hr, Wr;
     const float* smean; const float* sstd;   // affine after
+    const float* lo; const float* hi;        // clamp of the normalised value (saved-stat forward), may be null
 };
 __global__ void pointwise_k(const PointP p) {
     const long total = (long)p.B * p.H * p.W * (p.C >> 2);
@@ -224,6 +225,7 @@ __global__ void pointwise_k(const PointP p) {
         for (int e = 0; e < 4; ++e) {
             float t = pv[e];
             if (p.mean) t = p.div ? (t - p.mean[c4 + e]) / p.scale[c4 + e] : (t - p.mean[c4 + e]) * p.scale[c4 + e];
+            if (p.lo) t = fminf(p.hi[c4 + e], fmaxf(p.lo[c4 + e], t));
             if (p.res_mode == 1) t += p.res[((long)(y + 1) * (p.Wr + 2) + x + 1) * p.C + c4 + e];
             if (p.res_mode == 2)
                 t += p.res[((b * (p.Hr + 2) + (y >> 1) + 1) * (p.Wr + 2) + (x >> 1) + 1) * (long)p.C + c4 + e];

@@ -96,6 +96,8 @@ struct rrv_ctx {
     int active_src = -1;                       // style id whose state is folded (-2: blend)
     EncPlan enc_frame[RRV_MAX_SLOTS], enc_add, enc_style;
     DecPlan dec[RRV_MAX_SLOTS];
+    struct Feature { float* p; int H, W; };    // cached raw relu4_1 feature of one (padded) frame, H x W = frame size
+    std::vector<Feature> features;
     std::vector<float*> patches;               // relu4_1 features of added frames (ring layout images)
     int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
@@ -347,9 +349,9 @@ int chan_stats(rrv_handle h, const Tens& t, int mode, float* out) {
 }
 
 int pointwise(rrv_handle h, const Tens& x, Tens& y, const float* mean, const float* scale, bool div, const Tens* res,
-              int res_mode, const float* smean, const float* sstd) {
+              int res_mode, const float* smean, const float* sstd, const float* lo = nullptr, const float* hi = nullptr) {
     PointP p{x.p, y.p, x.B, x.H, x.W, x.C, mean, scale, div ? 1 : 0, res ? res->p : nullptr, res_mode,
-             res ? res->H : 0, res ? res->W : 0, smean, sstd};
+             res ? res->H : 0, res ? res->W : 0, smean, sstd, lo, hi};
     const long total = (long)x.B * x.H * x.W * (x.C / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
@@ -474,7 +476,8 @@ int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens
     return RRV_OK;
 }
 
-int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, float* d_out) {
+// feat != nullptr: skip the encoder and start from a cached raw relu4_1 feature (ring layout, [1,H/8,W/8,512])
+int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, float* d_out, const float* feat = nullptr) {
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
     if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
     if (h->active_src == -1) return fail(h, RRV_E_STATE, "state not computed: call compute() (or set_state) before transfer()");
@@ -491,7 +494,13 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     DecPlan& d = h->dec[slot];
     EncPlan& e = h->enc_frame[slot];
     const float* st = h->active;
-    RCHK(run_encoder(h, e, d_in, 0, st + SL.norm[N_DEC0]));
+    if (feat) {   // cached raw relu4_1 feature: Decoder.norm[0] (saved stats + clamp) as a pointwise step
+        Tens src; src.p = const_cast<float*>(feat); src.B = 1; src.H = H / 8; src.W = W / 8; src.C = 512;
+        const float* n0 = st + SL.norm[N_DEC0];
+        RCHK(pointwise(h, src, e.c41, n0, n0 + 512, false, nullptr, 0, nullptr, nullptr, n0 + 1024, n0 + 1536));
+    } else {
+        RCHK(run_encoder(h, e, d_in, 0, st + SL.norm[N_DEC0]));
+    }
     const Tens* cur = &e.c41;
     Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
     for (int f = 0; f < 3; ++f) {
@@ -646,6 +655,7 @@ int rrv_destroy(rrv_handle h) {
         if (kv.second.pk_wino) (void)hipFree(kv.second.pk_wino);
     }
     for (float* p : h->patches) (void)hipFree(p);
+    for (auto& f : h->features) if (f.p) (void)hipFree(f.p);
     for (EncPlan* e : {&h->enc_frame[0], &h->enc_frame[1], &h->enc_frame[2], &h->enc_frame[3], &h->enc_add, &h->enc_style})
         for (Tens* t : {&e->c11, &e->p1, &e->c21, &e->p2, &e->c31, &e->c32, &e->c33, &e->p3, &e->c41}) tfree(t);
     for (DecPlan& d : h->dec)
@@ -915,6 +925,86 @@ int rrv_transfer_batch(rrv_handle h, const uint8_t* frames, int B, int H, int W,
 int rrv_transfer_blend(rrv_handle h, const uint8_t* frame, int H, int W, const float* wts, int ns, float* out) {
     if (!wts) return RRV_E_ARG;
     return host_roundtrip(h, frame, 1, H, W, out, wts, ns);
+}
+
+// ---- multi-style feature API ("Multi-style Interpolation/stylization.py":66-100): the reference caches the
+// encoder output of every frame on disk (test.py:87-101) and feeds it back; here the cache lives in HBM.
+int rrv_generate_content_features(rrv_handle h, const uint8_t* frame, int H, int W, int* feature_id) {
+    if (!h || !frame || !feature_id) return RRV_E_ARG;
+    if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
+    if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "generate_content_features: frame too small");
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    RCHK(ensure_u8(h, (size_t)H * W * 3));
+    HIPCHK(hipMemcpyAsync(h->d_u8, frame, (size_t)H * W * 3, hipMemcpyHostToDevice, h->stream));
+    RCHK(enc_plan(h, h->enc_add, 1, H, W));
+    RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr));
+    const Tens& f = h->enc_add.c41;
+    rrv_ctx::Feature ft{nullptr, H, W};
+    const size_t slack = (size_t)20 * (f.W + 2 + 20) * 512;      // same slack as talloc: tile-overrun reads stay inside
+    RCHK(dalloc(h, &ft.p, f.img_floats() + slack, true));
+    HIPCHK(hipMemcpyAsync(ft.p, f.p, f.img_floats() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->features.push_back(ft);
+    *feature_id = (int)h->features.size() - 1;
+    return RRV_OK;
+}
+
+int rrv_add_patch(rrv_handle h, int feature_id) {
+    if (!h || feature_id < 0 || feature_id >= (int)h->features.size() || !h->features[feature_id].p) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    const rrv_ctx::Feature& ft = h->features[feature_id];
+    if (!h->patches.empty() && (ft.H != h->add_H || ft.W != h->add_W))
+        return fail(h, RRV_E_ARG, "add_patch: all sampled features must have the same size");
+    Tens f; f.B = 1; f.H = ft.H / 2 / 2 / 2; f.W = ft.W / 2 / 2 / 2; f.C = 512;
+    float* keep = nullptr;
+    RCHK(dalloc(h, &keep, f.img_floats(), false));
+    HIPCHK(hipMemcpy(keep, ft.p, f.img_floats() * sizeof(float), hipMemcpyDeviceToDevice));
+    h->patches.push_back(keep);
+    h->patch_h = f.H; h->patch_w = f.W; h->add_H = ft.H; h->add_W = ft.W;
+    return RRV_OK;
+}
+
+int rrv_transfer_features(rrv_handle h, int feature_id, const float* wts, int ns, float* out) {
+    if (!h || !wts || !out || ns < 1 || ns > RRV_MAX_STYLES) return RRV_E_ARG;
+    if (feature_id < 0 || feature_id >= (int)h->features.size() || !h->features[feature_id].p) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    const rrv_ctx::Feature& ft = h->features[feature_id];
+    if ((ft.H % 8) || (ft.W % 8)) return fail(h, RRV_E_ARG, "transfer: feature of a frame whose sides are not multiples of 8");
+    BlendP bp{};
+    bp.n = ns; bp.out = h->active; bp.count = RRV_STATE_FLOATS;
+    for (int s = 0; s < ns; ++s) {
+        if (!h->styles[s].computed) return fail(h, RRV_E_STATE, "blend: state not computed for every style");
+        bp.st[s] = h->styles[s].blob; bp.w[s] = wts[s];
+    }
+    hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
+    HIPCHK(hipGetLastError());
+    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
+    h->active_src = -2;
+    const size_t n = (size_t)ft.H * ft.W * 3;
+    if (h->d_outf_cap < n) {
+        if (h->d_outf) (void)hipFree(h->d_outf);
+        h->d_outf = nullptr; h->d_outf_cap = 0;
+        HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
+        h->d_outf_cap = n;
+    }
+    h->next_slot = 0;
+    RCHK(transfer_device(h, nullptr, 1, ft.H, ft.W, h->d_outf, ft.p));
+    h->next_slot = 0;
+    HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
+    HIPCHK(hipStreamSynchronize(h->streams[0]));
+    return RRV_OK;
+}
+
+int rrv_release_features(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    for (auto& f : h->features) if (f.p) (void)hipFree(f.p);
+    h->features.clear();
+    return RRV_OK;
 }
 
 // Stylization(use_Global=False).transfer (test/framework.py:106-118 with test/style_network_frame.py):

@@ -174,3 +174,41 @@ class Stylization():
             self._chk(self._lib.rrv_profile_entry(self._h, i, C.byref(name), C.byref(ms), C.byref(fl), C.byref(by), C.byref(fx)))
             rows.append((name.value.decode(), ms.value, fl.value, by.value, fx.value))
         return rows
+
+
+class ContentFeature():
+    """Handle to an encoder output cached in HBM (what the reference stores as cache/%d.pt)."""
+
+    def __init__(self, fid, shape):
+        self.id, self.shape = fid, shape
+
+
+class MultiStyleStylization(Stylization):
+    """Mirror of "Multi-style Interpolation/stylization.py":42-100: ``Stylization(checkpoint, cuda, style_num)``
+    with ``prepare_style(list)``, ``generate_content_features(img)``, ``add_patch(feature)``,
+    ``compute_norm()``, ``clean()`` and ``transfer(feature, style_weight)``."""
+
+    def __init__(self, checkpoint="", cuda=True, style_num=1, device=None):
+        super().__init__(checkpoint, cuda=cuda, use_Global=True, device=device, style_num=style_num)
+
+    def generate_content_features(self, content):
+        a = _u8_image(content, "content")
+        fid = C.c_int(-1)
+        self._chk(self._lib.rrv_generate_content_features(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], C.byref(fid)))
+        return ContentFeature(fid.value, a.shape)
+
+    def add_patch(self, patch_feature):
+        self._chk(self._lib.rrv_add_patch(self._h, patch_feature.id))
+
+    def compute_norm(self):
+        self.compute()
+
+    def transfer(self, cur_feature, style_weight=[1.]):
+        H, W = cur_feature.shape[:2]
+        out = np.empty((H, W, 3), dtype=np.float32)
+        w = (C.c_float * len(style_weight))(*[float(v) for v in style_weight])
+        self._chk(self._lib.rrv_transfer_features(self._h, cur_feature.id, w, len(style_weight), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def release_features(self):
+        self._chk(self._lib.rrv_release_features(self._h))

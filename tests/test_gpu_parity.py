@@ -201,3 +201,29 @@ def test_white_noise_frames_vs_oracle(pkg, oracle, weights):
     assert_pre_close(s.preclamp(256, 256), o.transfer(frame, return_preclamp=True)[0])
     assert np.abs(out - o.transfer(frame)).max() <= IMG_ATOL
     s.close()
+
+
+def test_multistyle_feature_api_matches_reference(pkg, weights, oracle):
+    """"Multi-style Interpolation/stylization.py" call surface: features cached in HBM, decoder-only transfer."""
+    g = load_golden("multistyle_s2")
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7), pkg.synth_style(64, 64, kind="smooth", seed=8)]
+    frames = [pkg.synth_frame(i, 64, 48, kind="smooth") for i in range(3)]
+    padded = [oracle.reflect_pad(f, 192, 192) for f in frames]
+    s = pkg.MultiStyleStylization(weights, cuda=True, style_num=2)
+    s.prepare_style(styles)
+    feats = [s.generate_content_features(p) for p in padded]
+    s.clean()
+    for i in (0, 2):
+        s.add_patch(feats[i])
+    s.compute_norm()
+    assert_state_close(s.get_state(0), g["state0"], "style 0")
+    assert_state_close(s.get_state(1), g["state1"], "style 1")
+    wts = [float(v) for v in g["weights"]]
+    out = s.transfer(feats[1], wts)
+    assert_pre_close(s.preclamp(192, 192)[64:128, 64:112], g["pre_crop"])
+    assert np.abs(out[64:128, 64:112] - g["out_crop"]).max() <= IMG_ATOL
+    # decoder-only path == full path on the same frame (same arithmetic after the encoder)
+    full = pkg.Stylization.transfer(s, padded[1], style_weight=wts)
+    assert np.abs(full - out).max() <= 1e-3
+    s.release_features()
+    s.close()
