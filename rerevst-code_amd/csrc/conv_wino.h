@@ -179,6 +179,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
             if (c + 1 < nchunks) stage_u(c + 1);          // U buffer (c+1)&1: last read in iteration c-1
             if (c + 2 < nchunks) stage_raw(c + 2);        // raw buffer c&1: its patch was read in iteration c-1
         }
+        if (ABL & 128) {   // microbench only: the MFMA stream alone (no LDS reads, no transform)
+            f32x4 u0 = vcur[0], u1 = vcur[1];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 vv = vcur[i];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[s], vv[s], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[s], vv[s], acc[i][1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vnext[i] = vcur[i];
+            return;
+        }
         const unsigned ub = PAR ? offU1 : offU;
         constexpr int RB = (1 - PAR) * WINO_RAW_BYTES;    // raw buffer (c+1)&1
         f32x4 u[4][2];       // U fragments in flight, slot = pos & 3

@@ -70,9 +70,9 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
           u4 = run<BN, 9, E_RELU, 1, 4, 0>(p, it), u5 = run<BN, 9, E_RELU, 4, 4, 0>(p, it);
     printf("%-28s bufferlds %.1f TF | BM256 %.1f | BM256+bufferlds %.1f | BM256 noload %.1f | BM256 nostore %.1f\n", name, fl / u1 / 1e9, fl / u2 / 1e9,
            fl / u3 / 1e9, fl / u4 / 1e9, fl / u5 / 1e9);
-    float w0 = run_wino<0>(p, it), w1 = run_wino<1>(p, it), w2 = run_wino<2>(p, it), w4 = run_wino<4>(p, it), w7 = run_wino<7>(p, it), wx = run_wino<0>(p, it, 1);
-    printf("%-28s WINOGRAD %.3f ms = %.1f TF-equivalent (direct FLOPs) | noload %.1f | nobarrier %.1f | nostore %.1f | none %.1f | XCD-SLABS %.1f\n", name, w0,
-           fl / w0 / 1e9, fl / w1 / 1e9, fl / w2 / 1e9, fl / w4 / 1e9, fl / w7 / 1e9, fl / wx / 1e9);
+    float w0 = run_wino<0>(p, it), w1 = run_wino<1>(p, it), w2 = run_wino<2>(p, it), w4 = run_wino<4>(p, it), w7 = run_wino<7>(p, it), wx = run_wino<0>(p, it, 1), wm = run_wino<128 + 7>(p, it, 1);
+    printf("%-28s WINOGRAD %.3f ms = %.1f TF-equivalent (direct FLOPs) | noload %.1f | nobarrier %.1f | nostore %.1f | none %.1f | XCD-SLABS %.1f | MFMA-only %.1f\n", name, w0,
+           fl / w0 / 1e9, fl / w1 / 1e9, fl / w2 / 1e9, fl / w4 / 1e9, fl / w7 / 1e9, fl / wx / 1e9, fl / wm / 1e9);
     printf("%-28s base %.3f ms %.1f TF | noload %.1f | nobarrier %.1f | noload+nobar %.1f | nostore %.1f | none %.1f TF  (WGs=%d)\n", name, t0,
            fl / t0 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9, fl / t3 / 1e9, fl / t4 / 1e9, fl / t7 / 1e9,
            p.tiles_x * p.tiles_y * B * (Cout / BN));
