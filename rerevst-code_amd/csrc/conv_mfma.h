@@ -85,6 +85,15 @@ __device__ __forceinline__ void bufld16(const void* base, char* lds_wave_base, i
 #endif
 }
 
+// Same with an enable flag folded into the descriptor: num_records = 0 makes every lane out of range, which the
+// hardware turns into "no fetch, zeros written" — a wave-uniform condition without a branch in the MFMA stream.
+__device__ __forceinline__ void bufld16_if(bool en, const void* base, char* lds_wave_base, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, en ? 0x7fffffff : 0, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+#endif
+}
+
 // ABL is for tools/conv_microbench.hip only (ablations: 1 = no loads after the first stage,
 // 2 = no barriers, 4 = no stores); the library always instantiates ABL = 0.
 // MSUB overrides the number of M-subtiles per wave (tile rows = WAVES_M * MSUB * 2); LD selects the

@@ -30,10 +30,35 @@
 #include <type_traits>
 #include "conv_mfma.h"
 
-#define WINO_RAW_BYTES 24576            /* 18*18 pixels * 64 B = 1296 pieces, rounded up to 6 x 256 */
+#ifndef WINO_PIN
+#define WINO_PIN 0
+#endif
+#ifndef WINO_NT
+#define WINO_NT 0
+#endif
+#if WINO_NT
+#define WINO_STORE(ptr, v) __builtin_nontemporal_store(v, ptr)
+#else
+#define WINO_STORE(ptr, v) (*(ptr) = (v))
+#endif
 #define WINO_U_BYTES 32768              /* 16 positions * 32 couts * 16 channels * 4 B */
 #define WINO_PAR_BYTES 2048             /* per-channel epilogue parameters of the item's 32 couts: 11 vectors x 128 B */
-#define WINO_SMEM_BYTES (2 * WINO_RAW_BYTES + 2 * WINO_U_BYTES + WINO_PAR_BYTES)   /* 114 KB: one workgroup per CU */
+// A workgroup is 16x16 output pixels x 32 output channels, run by NW = 4 or 8 waves.  NW = 4: wave w owns tile
+// group w (4 x 16 pixels) and both 16-channel blocks.  NW = 8: waves 2g and 2g+1 share tile group g and own one
+// 16-channel block each (64 accumulators, two waves per SIMD that fill each other's issue gaps).
+template <int NW>
+struct WinoGeo {
+    static constexpr int NT = NW * 64;                       // threads
+    static constexpr int NB = NW == 8 ? 1 : 2;               // 16-cout blocks per wave
+    static constexpr int HALF = 18 * 9;                      // halo pixels in even (= odd) columns
+    static constexpr int PIECES = 2 * HALF * 4;              // 16-byte pieces of one 16-channel raw halo tile (1296)
+    static constexpr int RAW_IT = (PIECES + NT - 1) / NT;    // LDS-DMA instructions per thread per raw tile
+    static constexpr int RAW_BYTES = 24576;                  // 1296 pieces rounded up to 1536
+    static constexpr int U_IT = WINO_U_BYTES / (NT * 16);
+    static constexpr int SMEM = 2 * RAW_BYTES + 2 * WINO_U_BYTES + WINO_PAR_BYTES;   // 114 KB: one workgroup per CU
+};
+#define WINO_RAW_BYTES (WinoGeo<4>::RAW_BYTES)
+#define WINO_SMEM_BYTES (WinoGeo<4>::SMEM)
 
 // LDS reads of the hand-pipelined main loop: issued early by inline asm, released by counted
 // s_waitcnt lgkmcnt(N) (LDS returns in order), so the single wave per SIMD never parks on LDS latency.
@@ -58,85 +83,101 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-// reads issued in main-loop iteration i: U fragments of position i+2 (2) and, for i<8, two patch pieces
-__host__ __device__ constexpr int wino_issued(int i) { return (i + 2 < 16 ? 2 : 0) + (i < 8 ? 2 : 0); }
+// reads issued in main-loop iteration i: U fragments of position i+2 (nb of them) and, for i<8, two patch pieces
+__host__ __device__ constexpr int wino_issued(int i, int nb) { return (i + 2 < 16 ? nb : 0) + (i < 8 ? 2 : 0); }
 // LDS reads younger than U(i) when iteration i waits for it
-__host__ __device__ constexpr int wino_younger(int i) {
-    return i == 0 ? 2 + wino_issued(0)
-         : i == 1 ? wino_issued(0) + wino_issued(1)
-                  : (i - 2 < 8 ? 2 : 0) + wino_issued(i - 1) + wino_issued(i);
+__host__ __device__ constexpr int wino_younger(int i, int nb) {
+    return i == 0 ? nb + wino_issued(0, nb)
+         : i == 1 ? wino_issued(0, nb) + wino_issued(1, nb)
+                  : (i - 2 < 8 ? 2 : 0) + wino_issued(i - 1, nb) + wino_issued(i, nb);
 }
 
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
+template <int EPI, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
+    using G = WinoGeo<NW>;
+    constexpr int RAW_BYTES = G::RAW_BYTES, NT = G::NT, NB = G::NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
     const int lane = tid & 63, t = lane & 15, q = lane >> 4;
     const int tr = t >> 3, tc = t & 7;
+    const int tg = NW == 8 ? wave >> 1 : wave;          // tile group: output rows 4*tg .. 4*tg+3 of the workgroup tile
+    const int nb0 = NW == 8 ? wave & 1 : 0;             // first 16-cout block of this wave
     const int nchunks = p.Cin >> 4;      // even (Cin >= 64)
     const int n_ntiles = p.Cout >> 5;
 
-    // ---- per-tile state of the tile being LOADED (the persistent loop prefetches one tile ahead)
-    int y0 = 0, x0 = 0, b = 0, n_tile = 0;
-    const float* in_b = p.in;
-    const float* w_tile = p.wpk;
-    int asrc[6];
-    // Work item of this workgroup in round r.  Workgroup w runs on XCD w % 8 (observed dispatch order; used
-    // for locality only).  p.xcd_slabs != 0: the S cout slabs of one pixel tile are given to workgroups of
-    // the SAME XCD in the same round, so the raw input tile is fetched from HBM once and then hits that XCD's
-    // L2 (otherwise every XCD owns one slab — its U stays L2-resident — and re-fetches every input tile).
-    const int n_pix = p.tiles_x * p.tiles_y * p.B;
-    auto setup = [&](int round) -> bool {
-        int pix;
-        const int G = gridDim.x, w = blockIdx.x;
+    // ---- work items.  Workgroup w runs on XCD w % 8 (observed dispatch order; used for locality only).
+    // p.xcd_slabs != 0: the S cout slabs of one pixel tile are given to workgroups of the SAME XCD in the same
+    // round, so the raw input tile is fetched from HBM once and then hits that XCD's L2 (otherwise every XCD owns
+    // one slab — its U stays L2-resident — and re-fetches every input tile).  The walk is incremental: all the
+    // divisions happen once, a round advances (tx, ty, b, slab) with carries on scalars.
+    struct Item { int tx, ty, b, nt; };
+    Item cur, nxt, dlt;
+    {
+        const int GD = gridDim.x, w = blockIdx.x;
+        int pix, dpix;
         if (p.xcd_slabs) {
-            const int PT = (G >> 3) / n_ntiles;            // pixel tiles per XCD per round
-            pix = (round * 8 + (w & 7)) * PT + (w >> 3) / n_ntiles;
-            n_tile = (w >> 3) % n_ntiles;
+            const int PT = (GD >> 3) / n_ntiles;            // pixel tiles per XCD per round
+            pix = (w & 7) * PT + (w >> 3) / n_ntiles; dpix = 8 * PT;
+            cur.nt = (w >> 3) % n_ntiles; dlt.nt = 0;
         } else {
-            const int item = w + round * G;
-            n_tile = item % n_ntiles;
-            pix = item / n_ntiles;
+            cur.nt = w % n_ntiles; pix = w / n_ntiles;
+            dlt.nt = GD % n_ntiles; dpix = GD / n_ntiles;
         }
-        if (pix >= n_pix) return false;
-        int r = pix;
-        const int tx = r % p.tiles_x;
-        r /= p.tiles_x;
-        const int ty = r % p.tiles_y;
-        b = r / p.tiles_y;
-        y0 = ty * 16; x0 = tx * 16;
-        in_b = p.in + (size_t)b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
-        w_tile = p.wpk + (size_t)n_tile * nchunks * (16 * 32 * 16);
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            // LDS pixel slot P: even halo columns first, then odd ones (162 slots each), row-major inside;
-            // stored piece qq holds channels 4*(qq ^ ((hx>>1)&3)).. : conflict-free for the stride-2 patch reads
-            const int e = it * 256 + tid;
-            int P = e >> 2;
-            const int qq = e & 3;
-            if (P >= 324) P = 0;
-            const int half = P >= 162, rem = P - half * 162;
-            const int hy = rem / 9, hx = 2 * (rem - hy * 9) + half;
-            asrc[it] = (((y0 + hy) * (p.Wi + 2) + (x0 + hx)) * p.Cin + 4 * (qq ^ ((hx >> 1) & 3))) * 4;
-        }
-        return true;
+        cur.tx = pix % p.tiles_x; cur.ty = (pix / p.tiles_x) % p.tiles_y; cur.b = pix / (p.tiles_x * p.tiles_y);
+        dlt.tx = dpix % p.tiles_x; dlt.ty = (dpix / p.tiles_x) % p.tiles_y; dlt.b = dpix / (p.tiles_x * p.tiles_y);
+    }
+    auto advance = [&](const Item& a) {
+        Item r = a;
+        r.nt += dlt.nt;
+        int carry = 0;
+        if (r.nt >= n_ntiles) { r.nt -= n_ntiles; carry = 1; }
+        r.tx += dlt.tx + carry;
+        if (r.tx >= p.tiles_x) { r.tx -= p.tiles_x; r.ty += 1; }
+        r.ty += dlt.ty;
+        if (r.ty >= p.tiles_y) { r.ty -= p.tiles_y; r.b += 1; }
+        r.b += dlt.b;
+        return r;
     };
-    auto stage_u = [&](int chunk) {
-        char* udst = smem + 2 * WINO_RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
+    // scalar bases of an item: its input tile origin (the per-thread halo offsets asrc[] are tile-relative and
+    // never change) and its U slab
+    auto in_of = [&](const Item& a) {
+        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)((a.ty * 16) * (p.Wi + 2) + a.tx * 16) * p.Cin;
+    };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (16 * 32 * 16); };
+    int asrc[G::RAW_IT];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) bufld16(w_tile, udst + (it * 256 + wave * 64) * 16, tid * 16, chunk * WINO_U_BYTES + it * 4096);
+    for (int it = 0; it < G::RAW_IT; ++it) {
+        // LDS pixel slot P: even halo columns first, then odd ones (HALF slots each), row-major inside;
+        // stored piece qq holds channels 4*(qq ^ ((hx>>1)&3)).. : conflict-free for the stride-2 patch reads
+        const int e = it * NT + tid;
+        int P = e >> 2;
+        const int qq = e & 3;
+        if (P >= 2 * G::HALF) P = 0;
+        const int half = P >= G::HALF, rem = P - half * G::HALF;
+        const int hy = rem / 9, hx = 2 * (rem - hy * 9) + half;
+        asrc[it] = ((hy * (p.Wi + 2) + hx) * p.Cin + 4 * (qq ^ ((hx >> 1) & 3))) * 4;
+    }
+    bool have = cur.b < p.B, have_nxt = false;
+    const float* in_t = in_of(cur);
+    const float* w_t = w_of(cur);
+    const float* in_n = in_t;
+    const float* w_n = w_t;
+    auto stage_u = [&](int chunk) {
+        char* udst = smem + 2 * RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
+#pragma unroll
+        for (int it = 0; it < G::U_IT; ++it) bufld16(w_t, udst + (it * NT + wave * 64) * 16, tid * 16, chunk * WINO_U_BYTES + it * NT * 16);
     };
     auto stage_raw = [&](int chunk) {
-        char* rdst = smem + (chunk & 1) * WINO_RAW_BYTES;
+        char* rdst = smem + (chunk & 1) * RAW_BYTES;
 #pragma unroll
-        for (int it = 0; it < 6; ++it)
-            if (it < 5 || wave == 0) bufld16(in_b, rdst + (it * 256 + wave * 64) * 16, asrc[it], chunk * 64);
+        for (int it = 0; it < G::RAW_IT; ++it)
+            if (it * NT + wave * 64 < G::PIECES) bufld16(in_t, rdst + (it * NT + wave * 64) * 16, asrc[it], chunk * 64);
     };
 
     // per-channel epilogue parameters of the item's cout slab, parked in LDS while the K loop runs:
     // rows of 32 floats: 0 bias | 1-4 n1 (mean, rstd, lo, hi) | 5-8 n2 | 9-10 style mean, std
-    char* const par = smem + 2 * WINO_RAW_BYTES + 2 * WINO_U_BYTES;
+    char* const par = smem + 2 * RAW_BYTES + 2 * WINO_U_BYTES;
     auto stage_params = [&](int ntile) {
         if (wave < 2) {
             const int e = tid;                       // 16-byte piece: row e>>3, floats 4*(e&7)..
@@ -159,15 +200,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
     for (int dx = 0; dx < 4; ++dx)
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) {
-            const int hy = 4 * wave + 2 * tr + dy, hx = 2 * tc + dx;
-            const int P = (hx & 1) * 162 + hy * 9 + (hx >> 1);
+            const int hy = 4 * tg + 2 * tr + dy, hx = 2 * tc + dx;
+            const int P = (hx & 1) * G::HALF + hy * 9 + (hx >> 1);
             offD[dx * 4 + dy] = lds0 + P * 64 + ((q ^ ((hx >> 1) & 3)) << 4);
         }
-    const unsigned offU = lds0 + 2 * WINO_RAW_BYTES + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);
+    const unsigned offU = lds0 + 2 * RAW_BYTES + nb0 * 1024 + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);
     const unsigned offU1 = offU + WINO_U_BYTES;
 
-    f32x4 acc[16][2];
-    f32x4 va[16], vb[16];   // transformed input B^T d B of the current / next chunk (ping-pong)
+    f32x4 acc[16][NB];
+    // transformed input B^T d B of the current / next chunk (ping-pong); V[r][k] lives in element k*4 + r: the
+    // raw patch is read straight into the "next" array and both transform passes run in place
+    f32x4 va[16], vb[16];
+    auto col_pass = [](f32x4 (&d)[16], int dx) {       // d[dx*4 + dy] -> (B^T d)[r][dx] at d[dx*4 + r]
+        const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
+        d[dx * 4 + 0] = d0 - d2; d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = d2 - d1; d[dx * 4 + 3] = d1 - d3;
+    };
+    auto row_pass = [](f32x4 (&d)[16], int r) {        // (B^T d)[r][.] -> V[r][k] at d[k*4 + r]
+        const f32x4 d0 = d[0 + r], d1 = d[4 + r], d2 = d[8 + r], d3 = d[12 + r];
+        d[0 + r] = d0 - d2; d[4 + r] = d1 + d2; d[8 + r] = d2 - d1; d[12 + r] = d1 - d3;
+    };
 
     // One chunk: MFMAs of chunk c with V(c) = vcur, while the raw patch of chunk c+1 is read and
     // transformed into vnext.  Issue order per iteration i: U(i+2) x2, then (i<8) patch pieces 2i, 2i+1.
@@ -175,36 +226,47 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
     // buffer selection folds into the 16-bit immediate of every ds_read: no address arithmetic in the loop
     auto chunk_body = [&](int c, auto par_c, f32x4 (&vcur)[16], f32x4 (&vnext)[16]) {
         constexpr int PAR = decltype(par_c)::value;
-        if (!(ABL & 1)) {
-            if (c + 1 < nchunks) stage_u(c + 1);          // U buffer (c+1)&1: last read in iteration c-1
-            if (c + 2 < nchunks) stage_raw(c + 2);        // raw buffer c&1: its patch was read in iteration c-1
-        }
+        // U(c+1) goes to U buffer (c+1)&1 (last read in chunk c-1), raw(c+2) to raw buffer c&1 (its patch was read
+        // in chunk c-1).  Past the end of the item the same slots carry the NEXT item's U(0), raw(0), raw(1) (nchunks
+        // is even, so the buffer parities line up): the K loops of consecutive items form one stream.  The LDS-DMA
+        // instructions are spread over the first iterations of the MFMA loop: the four waves share one address
+        // unit (~16 clk per 1 KB instruction); issued back to back they stall there.
+        const bool own_u = c + 1 < nchunks, own_r = c + 2 < nchunks;
+        const bool en_u = own_u || have_nxt, en_r = own_r || have_nxt;
+        const float* const ubase = own_u ? w_t : w_n;
+        const float* const rbase = own_r ? in_t : in_n;
+        const int usoff = own_u ? (c + 1) * WINO_U_BYTES : 0;
+        const int rsoff = (own_r ? c + 2 : c + 2 - nchunks) * 64;
+        char* const udst = smem + 2 * RAW_BYTES + (1 - PAR) * WINO_U_BYTES;
+        char* const rdst = smem + PAR * RAW_BYTES;
         if (ABL & 128) {   // microbench only: the MFMA stream alone (no LDS reads, no transform)
-            f32x4 u0 = vcur[0], u1 = vcur[1];
+            f32x4 u01[2] = {vcur[0], vcur[1]};
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const f32x4 vv = vcur[i];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[s], vv[s], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[s], vv[s], acc[i][1], 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u01[nb][s], vv[s], acc[i][nb], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) vnext[i] = vcur[i];
             return;
         }
         const unsigned ub = PAR ? offU1 : offU;
-        constexpr int RB = (1 - PAR) * WINO_RAW_BYTES;    // raw buffer (c+1)&1
-        f32x4 u[4][2];       // U fragments in flight, slot = pos & 3
-        f32x4 d[16];         // raw patch of the next chunk, index dx*4 + dy; becomes B^T d column by column
-        u[0][0] = lds_rd128<0>(ub); u[0][1] = lds_rd128<1024>(ub);
-        u[1][0] = lds_rd128<2048>(ub); u[1][1] = lds_rd128<2048 + 1024>(ub);
+        constexpr int RB = (1 - PAR) * RAW_BYTES;    // raw buffer (c+1)&1
+        f32x4 u[4][NB];      // U fragments in flight, slot = pos & 3
+        f32x4 (&d)[16] = vnext;   // raw patch of the next chunk, index dx*4 + dy; transformed in place
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            u[0][nb] = nb ? lds_rd128<1024>(ub) : lds_rd128<0>(ub);
+            u[1][nb] = nb ? lds_rd128<2048 + 1024>(ub) : lds_rd128<2048>(ub);
+        }
         static_for([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if constexpr (i + 2 < 16) {
                 u[(i + 2) & 3][0] = lds_rd128<(i + 2) * 2048>(ub);
-                u[(i + 2) & 3][1] = lds_rd128<(i + 2) * 2048 + 1024>(ub);
+                if constexpr (NB == 2) u[(i + 2) & 3][NB - 1] = lds_rd128<(i + 2) * 2048 + 1024>(ub);
             }
             if constexpr (i < 8) {
                 d[2 * i] = lds_rd128<RB>(offD[2 * i]);
@@ -215,93 +277,90 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
             if constexpr (i >= 4 && i <= 10 && (i % 2) == 0) {
                 // column dx = (i-4)/2 of the patch (pieces 4dx..4dx+3, issued in iterations 2dx, 2dx+1) is complete
                 constexpr int dx = (i - 4) / 2;
-                lds_release4<wino_younger(i)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
-                lds_release2<wino_younger(i)>(u[i & 3][0], u[i & 3][1]);
-            } else {
-                lds_release2<wino_younger(i)>(u[i & 3][0], u[i & 3][1]);
+                lds_release4<wino_younger(i, NB)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
             }
+            lds_release2<wino_younger(i, NB)>(u[i & 3][0], u[i & 3][NB - 1]);
             __builtin_amdgcn_sched_barrier(0);
-            const f32x4 vv = vcur[i];
+            if (!(ABL & 1)) {
+                if constexpr (i < G::U_IT)
+                    bufld16_if(en_u, ubase, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
+                if constexpr (i < G::RAW_IT)
+                    bufld16_if(en_r && (i * NT + wave * 64 < G::PIECES), rbase, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
+            }
+            const f32x4 vv = vcur[(i & 3) * 4 + (i >> 2)];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3][0][s], vv[s], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3][1][s], vv[s], acc[i][1], 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3][nb][s], vv[s], acc[i][nb], 0, 0, 0);
             // input transform of the next chunk, sliced under the MFMAs
-            if constexpr (i >= 4 && i <= 10 && (i % 2) == 0) {
-                constexpr int dx = (i - 4) / 2;
-                const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
-                d[dx * 4 + 0] = d0 - d2; d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = d2 - d1; d[dx * 4 + 3] = d1 - d3;
-            }
+            if constexpr (i >= 4 && i <= 10 && (i % 2) == 0) col_pass(d, (i - 4) / 2);
             if constexpr (i >= 11 && i <= 14) {
                 constexpr int r = i - 11;
-                vnext[r * 4 + 0] = d[0 + r] - d[8 + r]; vnext[r * 4 + 1] = d[4 + r] + d[8 + r];
-                vnext[r * 4 + 2] = d[8 + r] - d[4 + r]; vnext[r * 4 + 3] = d[4 + r] - d[12 + r];
+                row_pass(d, r);
+                // V is first USED in the next chunk body, after the barrier: without this pin the compiler sinks the
+                // whole transform out of the MFMA shadow into the head of that block
+                if (WINO_PIN) asm volatile("" : "+v"(d[0 + r]), "+v"(d[4 + r]), "+v"(d[8 + r]), "+v"(d[12 + r]));
             }
         }, std::make_integer_sequence<int, 16>{});
     };
 
-    // ---- persistent loop over (pixel tile, cout slab) work items; the next item's first tiles are in
-    // flight while the current item's epilogue runs
-    int round = 0;
-    bool have = setup(round);
+    // ---- persistent loop over (pixel tile, cout slab) work items.  Only the first item has a prologue: the last
+    // two chunks of every item request the next item's U(0), raw(0), raw(1), and the last chunk body, which reads
+    // and transforms "the next chunk's" patch, thereby leaves V(0) of the next item in va.
+    int par_ntile = -1;
+    long long tl[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
+    auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
+    if (ABL & 16) tl_t = clock64();
     if (have) {
         stage_raw(0);
         stage_u(0);
         stage_raw(1);
+        stage_params(cur.nt);
+        par_ntile = cur.nt;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) va[k] = *(const f32x4*)(smem + (offD[k] - lds0));
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) col_pass(va, dx);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row_pass(va, r);
     }
-    int par_ntile = -1;
     while (have) {
-        const int e_y0 = y0, e_x0 = x0, e_b = b, e_ntile = n_tile;
+        const int e_y0 = cur.ty * 16, e_x0 = cur.tx * 16, e_b = cur.b, e_ntile = cur.nt;
+        nxt = advance(cur);
+        have_nxt = nxt.b < p.B;
+        in_n = in_of(nxt);
+        w_n = w_of(nxt);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (par_ntile != e_ntile) {            // (never re-staged when gridDim.x is a multiple of the slab count)
-            if (par_ntile >= 0) __syncthreads();   // slower waves may still read the old slab's parameters
+            __syncthreads();                       // slower waves may still read the old slab's parameters
             stage_params(e_ntile);                 // lands before the first K-loop barrier
             par_ntile = e_ntile;
         }
-        __syncthreads();                      // raw(0), U(0), raw(1) landed
-        {   // V(0)
-            f32x4 d[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = *(const f32x4*)(smem + (offD[k] - lds0));
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
-                d[dx * 4 + 0] = d0 - d2; d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = d2 - d1; d[dx * 4 + 3] = d1 - d3;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {   // d[dx*4 + r] = (B^T d)[r][dx]
-                va[r * 4 + 0] = d[0 + r] - d[8 + r]; va[r * 4 + 1] = d[4 + r] + d[8 + r];
-                va[r * 4 + 2] = d[8 + r] - d[4 + r]; va[r * 4 + 3] = d[4 + r] - d[12 + r];
-            }
-        }
+        tick(0);                              // zero acc (+ previous epilogue tail)
         for (int c = 0; c < nchunks; c += 2) {
             chunk_body(c, std::integral_constant<int, 0>{}, va, vb);
             if (!(ABL & 2)) __syncthreads();      // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
             chunk_body(c + 1, std::integral_constant<int, 1>{}, vb, va);
             if (!(ABL & 2)) __syncthreads();
         }
-        // every LDS buffer is free now: start the next work item's loads before this item's epilogue
-        have = setup(++round);
-        if (have && !(ABL & 1)) {
-            stage_raw(0);
-            stage_u(0);
-            stage_raw(1);
-        }
-
+        tick(3);                              // K loop
+        // the next item's first tiles were requested by the last two chunks
+        cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;
         // ---- output transform + fused epilogue (all in registers)
         const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
         float* out_b = p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
         const float* res_b = nullptr;
         if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
-        const int yb = e_y0 + 4 * wave + 2 * tr, xb = e_x0 + 2 * tc;
-        f32x4 resv[2][2][2];     // residual values requested before the output transform hides their latency
+        const int yb = e_y0 + 4 * tg + 2 * tr, xb = e_x0 + 2 * tc;
+        f32x4 resv[NB][2][2];     // residual values requested before the output transform hides their latency
         if (EPI & (E_RES | E_RES_UPS)) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -310,12 +369,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
                         const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
                         resv[nb][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                         if (y < p.H && x < p.W)
-                            resv[nb][i][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + nb * 16 + 4 * q);
+                            resv[nb][i][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + (nb0 + nb) * 16 + 4 * q);
                     }
         }
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int co = e_ntile * 32 + nb * 16 + 4 * q;
+        for (int nb = 0; nb < NB; ++nb) {
+            const int co = e_ntile * 32 + (nb0 + nb) * 16 + 4 * q;
             f32x4 Y[2][2];
             {
                 f32x4 T[2][4];
@@ -330,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
                     Y[i][1] = T[i][1] - T[i][2] - T[i][3];
                 }
             }
-            const char* pl = par + (nb * 16 + 4 * q) * 4;      // this lane's 4 channels inside a 128-byte parameter row
+            const char* pl = par + ((nb0 + nb) * 16 + 4 * q) * 4;      // this lane's 4 channels inside a 128-byte parameter row
             const f32x4 bias = *(const f32x4*)(pl);
             f32x4 m1, r1, lo1, hi1, m2, r2, lo2, hi2, smean, sstd;
             if (EPI & E_NORM1) {
@@ -378,17 +437,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino_k(const ConvP p) {
                         }
                     } else if (valid) {
                         if (ABL & 4) { if (o[0] == 123.456f) out_b[co] = o[0]; }
-                        else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
+                        else WINO_STORE((f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co), o);
                     }
                 }
             if (EPI & E_POOL) {
                 const int y2 = yb >> 1, x2 = xb >> 1;
                 if (y2 < Ho && x2 < Wo) {
                     if (ABL & 4) { if (pooled[0] == 123.456f) out_b[co] = pooled[0]; }
-                    else *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
+                    else WINO_STORE((f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co), pooled);
                 }
             }
         }
+        tick(5);                              // epilogue issue
+    }
+    if ((ABL & 16) && lane == 0) {
+        long long* dbg = (long long*)p.n1;   // microbench passes a debug buffer here
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dbg[(blockIdx.x * NW + wave) * 6 + k] = tl[k];
     }
 }
 

@@ -26,19 +26,19 @@ float run(ConvP p, int iters) {
     return ms / iters;
 }
 
-template <int ABL>
+template <int ABL, int NW = 4>
 float run_wino(ConvP p, int iters, int xcd = 0) {
     p.xcd_slabs = xcd;
     p.tiles_y = (p.H + 15) / 16;
     int items = p.tiles_x * p.tiles_y * p.B * (p.Cout / 32);
     dim3 grid(items < 256 ? items : 256, 1);
-    CK(hipFuncSetAttribute((const void*)conv_wino_k<E_RELU, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_SMEM_BYTES));
+    CK(hipFuncSetAttribute((const void*)conv_wino_k<E_RELU, ABL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<NW>::SMEM));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL>), grid, dim3(256), WINO_SMEM_BYTES, 0, p);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL, NW>), grid, dim3(NW * 64), WinoGeo<NW>::SMEM, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL>), grid, dim3(256), WINO_SMEM_BYTES, 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL, NW>), grid, dim3(NW * 64), WinoGeo<NW>::SMEM, 0, p);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -48,8 +48,8 @@ float run_wino(ConvP p, int iters, int xcd = 0) {
 
 template <int BN>
 void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
-    const size_t in_f = (size_t)B * (H + 2) * (W + 2) * Cin + (size_t)20 * (W + 22) * Cin;
-    const size_t out_f = (size_t)B * (H + 2) * (W + 2) * Cout + (size_t)20 * (W + 22) * Cout;
+    const size_t in_f = (size_t)B * (H + 2) * (W + 2) * Cin + (size_t)40 * (W + 22) * Cin;
+    const size_t out_f = (size_t)B * (H + 2) * (W + 2) * Cout + (size_t)40 * (W + 22) * Cout;
     float *in, *out, *w, *bias;
     CK(hipMalloc(&in, in_f * 4)); CK(hipMalloc(&out, out_f * 4));
     CK(hipMalloc(&w, (size_t)Cout * Cin * 16 * 4)); CK(hipMemset(w, 0, (size_t)Cout * Cin * 16 * 4)); CK(hipMalloc(&bias, Cout * 4));
@@ -73,9 +73,32 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     float w0 = run_wino<0>(p, it), w1 = run_wino<1>(p, it), w2 = run_wino<2>(p, it), w4 = run_wino<4>(p, it), w7 = run_wino<7>(p, it), wx = run_wino<0>(p, it, 1), wm = run_wino<128 + 7>(p, it, 1);
     printf("%-28s WINOGRAD %.3f ms = %.1f TF-equivalent (direct FLOPs) | noload %.1f | nobarrier %.1f | nostore %.1f | none %.1f | XCD-SLABS %.1f | MFMA-only %.1f\n", name, w0,
            fl / w0 / 1e9, fl / w1 / 1e9, fl / w2 / 1e9, fl / w4 / 1e9, fl / w7 / 1e9, fl / wx / 1e9, fl / wm / 1e9);
+    {
+        float a0 = run_wino<0, 8>(p, it, 1), a1 = run_wino<1, 8>(p, it, 1), a2 = run_wino<2, 8>(p, it, 1), a4 = run_wino<4, 8>(p, it, 1), a7 = run_wino<7, 8>(p, it, 1);
+        printf("%-28s WINO 8 waves %.3f ms = %.1f TF-eq | noload %.1f | nobarrier %.1f | nostore %.1f | none %.1f\n", name, a0, fl / a0 / 1e9, fl / a1 / 1e9,
+               fl / a2 / 1e9, fl / a4 / 1e9, fl / a7 / 1e9);
+    }
     printf("%-28s base %.3f ms %.1f TF | noload %.1f | nobarrier %.1f | noload+nobar %.1f | nostore %.1f | none %.1f TF  (WGs=%d)\n", name, t0,
            fl / t0 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9, fl / t3 / 1e9, fl / t4 / 1e9, fl / t7 / 1e9,
            p.tiles_x * p.tiles_y * B * (Cout / BN));
+    {   // Winograd per-phase cycles (wave averages)
+        long long* dbg; CK(hipMalloc(&dbg, (size_t)256 * 8 * 6 * 8));
+        ConvP q = p; q.n1 = (const float*)dbg; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
+        int items = q.tiles_x * q.tiles_y * q.B * (q.Cout / 32);
+        dim3 grid(items < 256 ? items : 256, 1);
+        CK(hipFuncSetAttribute((const void*)conv_wino_k<E_RELU, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<4>::SMEM));
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((conv_wino_k<E_RELU, 16, 4>), grid, dim3(256), WinoGeo<4>::SMEM, 0, q);
+        CK(hipDeviceSynchronize());
+        std::vector<long long> h((size_t)grid.x * 4 * 6);
+        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double s[6] = {0}, tot = 0;
+        for (size_t i = 0; i < h.size(); ++i) { s[i % 6] += h[i]; tot += h[i]; }
+        const char* nm[6] = {"zero-acc", "item barrier", "V(0)", "K loop", "setup+prefetch", "epilogue"};
+        printf("     wino timeline (%% of wave time):");
+        for (int k = 0; k < 6; ++k) printf(" %s %.1f%% |", nm[k], 100.0 * s[k] / tot);
+        printf(" total %.0f clk/wave, %.1f items/WG\n", tot / (grid.x * 4), (double)items / grid.x);
+        CK(hipFree(dbg));
+    }
     {   // per-wave timeline (s_memtime): loop time vs epilogue time, and the spread of WG start times
         const int nw = p.tiles_x * p.tiles_y * B * (Cout / BN) * 4;
         long long* dbg; CK(hipMalloc(&dbg, (size_t)nw * 4 * 8));
