@@ -70,12 +70,26 @@ __device__ __forceinline__ f32x4 lds_rd128(unsigned addr) {     // LDS byte addr
     return r;
 }
 template <int N>
+__device__ __forceinline__ void lds_release1(f32x4& a) {   // (never pass one variable as two operands: the
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(N));   //  second one is copied BEFORE the wait)
+}
+template <int N>
 __device__ __forceinline__ void lds_release2(f32x4& a, f32x4& b) {   // a, b become valid here
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
 }
 template <int N>
 __device__ __forceinline__ void lds_release4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
+}
+
+// a - b on the packed-fp32 pipe (two v_pk_add_f32 with the neg modifier; the compiler only forms v_pk_add_f32 for
+// additions and would emit four v_sub_f32)
+__device__ __forceinline__ f32x4 f4sub(const f32x4 a, const f32x4 b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
 template <class F, int... I>
@@ -213,11 +227,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
     f32x4 va[16], vb[16];
     auto col_pass = [](f32x4 (&d)[16], int dx) {       // d[dx*4 + dy] -> (B^T d)[r][dx] at d[dx*4 + r]
         const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
-        d[dx * 4 + 0] = d0 - d2; d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = d2 - d1; d[dx * 4 + 3] = d1 - d3;
+        d[dx * 4 + 0] = f4sub(d0, d2); d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = f4sub(d2, d1); d[dx * 4 + 3] = f4sub(d1, d3);
     };
     auto row_pass = [](f32x4 (&d)[16], int r) {        // (B^T d)[r][.] -> V[r][k] at d[k*4 + r]
         const f32x4 d0 = d[0 + r], d1 = d[4 + r], d2 = d[8 + r], d3 = d[12 + r];
-        d[0 + r] = d0 - d2; d[4 + r] = d1 + d2; d[8 + r] = d2 - d1; d[12 + r] = d1 - d3;
+        d[0 + r] = f4sub(d0, d2); d[4 + r] = d1 + d2; d[8 + r] = f4sub(d2, d1); d[12 + r] = f4sub(d1, d3);
     };
 
     // One chunk: MFMAs of chunk c with V(c) = vcur, while the raw patch of chunk c+1 is read and
@@ -257,11 +271,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
         constexpr int RB = (1 - PAR) * RAW_BYTES;    // raw buffer (c+1)&1
         f32x4 u[4][NB];      // U fragments in flight, slot = pos & 3
         f32x4 (&d)[16] = vnext;   // raw patch of the next chunk, index dx*4 + dy; transformed in place
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            u[0][nb] = nb ? lds_rd128<1024>(ub) : lds_rd128<0>(ub);
-            u[1][nb] = nb ? lds_rd128<2048 + 1024>(ub) : lds_rd128<2048>(ub);
-        }
+        u[0][0] = lds_rd128<0>(ub);                      // issue order = completion order: U(0) blocks, then U(1)
+        if constexpr (NB == 2) u[0][NB - 1] = lds_rd128<1024>(ub);
+        u[1][0] = lds_rd128<2048>(ub);
+        if constexpr (NB == 2) u[1][NB - 1] = lds_rd128<2048 + 1024>(ub);
         static_for([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if constexpr (i + 2 < 16) {
@@ -279,7 +292,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
                 constexpr int dx = (i - 4) / 2;
                 lds_release4<wino_younger(i, NB)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
             }
-            lds_release2<wino_younger(i, NB)>(u[i & 3][0], u[i & 3][NB - 1]);
+            if constexpr (NB == 2) lds_release2<wino_younger(i, NB)>(u[i & 3][0], u[i & 3][1]);
+            else lds_release1<wino_younger(i, NB)>(u[i & 3][0]);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
                 if constexpr (i < G::U_IT)

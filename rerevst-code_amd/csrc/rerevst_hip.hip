@@ -193,14 +193,15 @@ void ups2_launch(const ConvP& p, dim3 grid, hipStream_t s) {
 #define UK(BN, EPI) {BN, 9, 1, EPI, &ups2_launch<BN, EPI>, "conv_ups2<" #BN "," #EPI ">"}
 const ConvKey UPS_TABLE[] = {UK(128, E_LRELU | E_NORM1), UK(64, E_LRELU | E_NORM1), UK(128, E_LRELU), UK(64, E_LRELU)};
 
+constexpr int WINO_NW = 8;     // waves per Winograd workgroup (conv_wino.h: 8 = two waves per SIMD, one 16-cout block each)
 template <int EPI>
 void wino_launch(const ConvP& p, dim3 grid, hipStream_t s) {
     static bool attr_set = false;     // >64 KB of dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wino_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, WINO_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<WINO_NW>::SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino_k<EPI>), grid, dim3(256), WINO_SMEM_BYTES, s, p);
+    hipLaunchKernelGGL((conv_wino_k<EPI, 0, WINO_NW>), grid, dim3(WINO_NW * 64), WinoGeo<WINO_NW>::SMEM, s, p);
 }
 #define WK(EPI) {32, 9, 0, EPI, &wino_launch<EPI>, "conv_wino<" #EPI ">"}
 const ConvKey WINO_TABLE[] = {

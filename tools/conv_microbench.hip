@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <math.h>
 #include "../rerevst-code_amd/csrc/conv_mfma.h"
 #include "../rerevst-code_amd/csrc/conv_wino.h"
 
@@ -81,6 +82,23 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     printf("%-28s base %.3f ms %.1f TF | noload %.1f | nobarrier %.1f | noload+nobar %.1f | nostore %.1f | none %.1f TF  (WGs=%d)\n", name, t0,
            fl / t0 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9, fl / t3 / 1e9, fl / t4 / 1e9, fl / t7 / 1e9,
            p.tiles_x * p.tiles_y * B * (Cout / BN));
+    {   // 8-wave form against the 4-wave form (same transforms, same summation order per accumulator)
+        ConvP q = p; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
+        int items = q.tiles_x * q.tiles_y * q.B * (q.Cout / 32);
+        dim3 grid(items < 256 ? items : 256, 1);
+        std::vector<float> o4(out_f), o8(out_f);
+        CK(hipMemset(out, 0, out_f * 4));
+        hipLaunchKernelGGL((conv_wino_k<E_RELU, 0, 4>), grid, dim3(256), WinoGeo<4>::SMEM, 0, q);
+        CK(hipMemcpy(o4.data(), out, out_f * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(out, 0, out_f * 4));
+        hipLaunchKernelGGL((conv_wino_k<E_RELU, 0, 8>), grid, dim3(512), WinoGeo<8>::SMEM, 0, q);
+        CK(hipMemcpy(o8.data(), out, out_f * 4, hipMemcpyDeviceToHost));
+        double md = 0; size_t bad = 0, first = 0;
+        for (size_t i = 0; i < out_f; ++i) { double d = fabs((double)o4[i] - o8[i]); if (d > 1e-5) { if (!bad) first = i; ++bad; } if (d > md) md = d; }
+        printf("     8-wave vs 4-wave: max |diff| %.3g, %zu mismatching of %zu", md, bad, out_f);
+        if (bad) { size_t pxl = first / Cout; printf(" first at ch %zu, x %zu, y %zu (o4 %.5f o8 %.5f)", first % Cout, pxl % (W + 2), (pxl / (W + 2)) % (H + 2), o4[first], o8[first]); }
+        printf("\n");
+    }
     {   // Winograd per-phase cycles (wave averages)
         long long* dbg; CK(hipMalloc(&dbg, (size_t)256 * 8 * 6 * 8));
         ConvP q = p; q.n1 = (const float*)dbg; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
