@@ -30,35 +30,50 @@
 #include <type_traits>
 #include "conv_mfma.h"
 
-#ifndef WINO_PIN
-#define WINO_PIN 0
-#endif
-#ifndef WINO_NT
-#define WINO_NT 0
-#endif
-#if WINO_NT
-#define WINO_STORE(ptr, v) __builtin_nontemporal_store(v, ptr)
-#else
-#define WINO_STORE(ptr, v) (*(ptr) = (v))
-#endif
-#define WINO_U_BYTES 32768              /* 16 positions * 32 couts * 16 channels * 4 B */
 #define WINO_PAR_BYTES 2048             /* per-channel epilogue parameters of the item's 32 couts: 11 vectors x 128 B */
 // A workgroup is 16x16 output pixels x 32 output channels, run by NW = 4 or 8 waves.  NW = 4: wave w owns tile
-// group w (4 x 16 pixels) and both 16-channel blocks.  NW = 8: waves 2g and 2g+1 share tile group g and own one
-// 16-channel block each (64 accumulators, two waves per SIMD that fill each other's issue gaps).
-template <int NW>
+// group w (4 x 16 output pixels) and both 16-channel blocks.  NW = 8: waves 2g and 2g+1 share tile group g and own
+// one 16-channel block each (64 accumulators, two waves per SIMD that fill each other's issue gaps).
+//
+// UPS = 0: F(2x2,3x3) on the input itself — 16 positions, 4x4 patches two pixels apart, 18x18 halo.
+// UPS = 1: nearest-x2 upsample fused with the 3x3 conv (ResidualBlock.conv1 behind Upsample,
+//   test/style_network_global.py:100-103,116-118).  One LOW-resolution pixel produces 2x2 outputs; per axis
+//     y[2i]   = g0 x[i-1] + (g1+g2) x[i]   = s x[i] + g0 (x[i-1] - x[i])
+//     y[2i+1] = (g0+g1) x[i] + g2 x[i+1]   = s x[i] + g2 (x[i+1] - x[i]),     s = g0+g1+g2
+//   i.e. 3 multiplies per 2 outputs: 9 positions per 2x2 outputs in 2-D (36 for the direct form, 16 for the
+//   parity-folded conv_ups2_k), 3x3 patches one pixel apart, 10x10 low-resolution halo, all coefficients +-1.
+template <int NW, int UPS>
 struct WinoGeo {
     static constexpr int NT = NW * 64;                       // threads
     static constexpr int NB = NW == 8 ? 1 : 2;               // 16-cout blocks per wave
-    static constexpr int HALF = 18 * 9;                      // halo pixels in even (= odd) columns
-    static constexpr int PIECES = 2 * HALF * 4;              // 16-byte pieces of one 16-channel raw halo tile (1296)
+    static constexpr int NP = UPS ? 9 : 16;                  // transform positions
+    static constexpr int PW = UPS ? 3 : 4;                   // patch width; pieces are indexed dx*PW + dy
+    static constexpr int NPIECE = PW * PW;
+    static constexpr int PPI = UPS ? 3 : 2;                  // patch pieces read per MFMA-loop iteration
+    static constexpr int TIN = UPS ? 8 : 16;                 // input pixels per workgroup tile edge
+    static constexpr int HALO = UPS ? 10 : 18;
+    static constexpr int HALF = 18 * 9;                      // UPS = 0: halo pixels in even (= odd) columns
+    static constexpr int PIECES = HALO * HALO * 4;           // 16-byte pieces of one 16-channel raw halo tile
     static constexpr int RAW_IT = (PIECES + NT - 1) / NT;    // LDS-DMA instructions per thread per raw tile
-    static constexpr int RAW_BYTES = 24576;                  // 1296 pieces rounded up to 1536
-    static constexpr int U_IT = WINO_U_BYTES / (NT * 16);
-    static constexpr int SMEM = 2 * RAW_BYTES + 2 * WINO_U_BYTES + WINO_PAR_BYTES;   // 114 KB: one workgroup per CU
+    static constexpr int RAW_BYTES = RAW_IT * NT * 16;       // 24576 / 8192
+    static constexpr int U_BYTES = NP * 32 * 16 * 4;         // 32768 / 18432
+    static constexpr int U_PIECES = U_BYTES / 16;
+    static constexpr int U_IT = (U_PIECES + NT - 1) / NT;
+    static constexpr int U_LDS = U_IT * NT * 16;             // LDS bytes per U buffer: a disabled LDS-DMA slot still writes zeros
+    static constexpr int SMEM = 2 * RAW_BYTES + 2 * U_LDS + WINO_PAR_BYTES;   // 114 KB (one workgroup per CU) / 58 KB
+    static constexpr int OCC = (UPS && NW == 4) ? 2 : 1;     // workgroups per CU
+    // MFMA-loop iteration in which column dx of the patch has landed (its last piece was issued three
+    // iterations earlier, before U(i)), and the iterations of the row passes
+    static constexpr int col_iter(int dx) { return (dx * PW + PW - 1) / PPI + 3; }
+    static constexpr int row_iter(int r) { return col_iter(PW - 1) + 1 + r; }
+    // LDS reads issued in iteration i: U fragments of position i+2 and up to PPI patch pieces
+    static constexpr int pieces_in(int i) { return i < 0 ? 0 : (NPIECE - i * PPI <= 0 ? 0 : (NPIECE - i * PPI < PPI ? NPIECE - i * PPI : PPI)); }
+    static constexpr int issued(int i) { return (i + 2 < NP ? NB : 0) + pieces_in(i); }
+    // LDS reads younger than U(i) when iteration i waits for it (LDS returns in order)
+    static constexpr int younger(int i) {
+        return i == 0 ? NB + issued(0) : i == 1 ? issued(0) + issued(1) : pieces_in(i - 2) + issued(i - 1) + issued(i);
+    }
 };
-#define WINO_RAW_BYTES (WinoGeo<4>::RAW_BYTES)
-#define WINO_SMEM_BYTES (WinoGeo<4>::SMEM)
 
 // LDS reads of the hand-pipelined main loop: issued early by inline asm, released by counted
 // s_waitcnt lgkmcnt(N) (LDS returns in order), so the single wave per SIMD never parks on LDS latency.
@@ -76,6 +91,10 @@ __device__ __forceinline__ void lds_release1(f32x4& a) {   // (never pass one va
 template <int N>
 __device__ __forceinline__ void lds_release2(f32x4& a, f32x4& b) {   // a, b become valid here
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_release3(f32x4& a, f32x4& b, f32x4& c) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "i"(N));
 }
 template <int N>
 __device__ __forceinline__ void lds_release4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
@@ -97,19 +116,10 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-// reads issued in main-loop iteration i: U fragments of position i+2 (nb of them) and, for i<8, two patch pieces
-__host__ __device__ constexpr int wino_issued(int i, int nb) { return (i + 2 < 16 ? nb : 0) + (i < 8 ? 2 : 0); }
-// LDS reads younger than U(i) when iteration i waits for it
-__host__ __device__ constexpr int wino_younger(int i, int nb) {
-    return i == 0 ? nb + wino_issued(0, nb)
-         : i == 1 ? wino_issued(0, nb) + wino_issued(1, nb)
-                  : (i - 2 < 8 ? 2 : 0) + wino_issued(i - 1, nb) + wino_issued(i, nb);
-}
-
-template <int EPI, int ABL = 0, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
-    using G = WinoGeo<NW>;
-    constexpr int RAW_BYTES = G::RAW_BYTES, NT = G::NT, NB = G::NB;
+template <int EPI, int ABL = 0, int NW = 4, int UPS = 0>
+__global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(const ConvP p) {
+    using G = WinoGeo<NW, UPS>;
+    constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, U_LDS = G::U_LDS, NT = G::NT, NB = G::NB, NP = G::NP, PW = G::PW, NPIECE = G::NPIECE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
@@ -156,21 +166,23 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
     // scalar bases of an item: its input tile origin (the per-thread halo offsets asrc[] are tile-relative and
     // never change) and its U slab
     auto in_of = [&](const Item& a) {
-        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)((a.ty * 16) * (p.Wi + 2) + a.tx * 16) * p.Cin;
+        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)((a.ty * G::TIN) * (p.Wi + 2) + a.tx * G::TIN) * p.Cin;
     };
-    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (16 * 32 * 16); };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NP * 32 * 16); };
     int asrc[G::RAW_IT];
 #pragma unroll
     for (int it = 0; it < G::RAW_IT; ++it) {
-        // LDS pixel slot P: even halo columns first, then odd ones (HALF slots each), row-major inside;
-        // stored piece qq holds channels 4*(qq ^ ((hx>>1)&3)).. : conflict-free for the stride-2 patch reads
+        // UPS = 0, LDS pixel slot P: even halo columns first, then odd ones (HALF slots each), row-major inside;
+        // stored piece qq holds channels 4*(qq ^ ((hx>>1)&3)).. : conflict-free for the stride-2 patch reads.
+        // UPS = 1: row-major 10x10, piece qq holds channels 4*(qq ^ (hx&3)): conflict-free for the stride-1 reads
         const int e = it * NT + tid;
         int P = e >> 2;
         const int qq = e & 3;
-        if (P >= 2 * G::HALF) P = 0;
-        const int half = P >= G::HALF, rem = P - half * G::HALF;
-        const int hy = rem / 9, hx = 2 * (rem - hy * 9) + half;
-        asrc[it] = ((hy * (p.Wi + 2) + hx) * p.Cin + 4 * (qq ^ ((hx >> 1) & 3))) * 4;
+        if (P >= G::HALO * G::HALO) P = 0;
+        int hy, hx, swz;
+        if (UPS) { hy = P / 10; hx = P - hy * 10; swz = hx & 3; }
+        else { const int half = P >= G::HALF, rem = P - half * G::HALF; hy = rem / 9; hx = 2 * (rem - hy * 9) + half; swz = (hx >> 1) & 3; }
+        asrc[it] = ((hy * (p.Wi + 2) + hx) * p.Cin + 4 * (qq ^ swz)) * 4;
     }
     bool have = cur.b < p.B, have_nxt = false;
     const float* in_t = in_of(cur);
@@ -178,9 +190,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
     const float* in_n = in_t;
     const float* w_n = w_t;
     auto stage_u = [&](int chunk) {
-        char* udst = smem + 2 * RAW_BYTES + (chunk & 1) * WINO_U_BYTES;
+        char* udst = smem + 2 * RAW_BYTES + (chunk & 1) * U_LDS;
 #pragma unroll
-        for (int it = 0; it < G::U_IT; ++it) bufld16(w_t, udst + (it * NT + wave * 64) * 16, tid * 16, chunk * WINO_U_BYTES + it * NT * 16);
+        for (int it = 0; it < G::U_IT; ++it)
+            if (it * NT + wave * 64 < G::U_PIECES) bufld16(w_t, udst + (it * NT + wave * 64) * 16, tid * 16, chunk * U_BYTES + it * NT * 16);
     };
     auto stage_raw = [&](int chunk) {
         char* rdst = smem + (chunk & 1) * RAW_BYTES;
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
 
     // per-channel epilogue parameters of the item's cout slab, parked in LDS while the K loop runs:
     // rows of 32 floats: 0 bias | 1-4 n1 (mean, rstd, lo, hi) | 5-8 n2 | 9-10 style mean, std
-    char* const par = smem + 2 * RAW_BYTES + 2 * WINO_U_BYTES;
+    char* const par = smem + 2 * RAW_BYTES + 2 * U_LDS;
     auto stage_params = [&](int ntile) {
         if (wave < 2) {
             const int e = tid;                       // 16-byte piece: row e>>3, floats 4*(e&7)..
@@ -209,36 +222,45 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
     // LDS byte addresses: this lane's 4x4 raw patch (slot P, 16-byte piece q, XOR swizzle), relative to
     // the raw buffer; and its U fragment (row = pos*32 + nb*16 + t, (row>>2)&3 == (t>>2)&3)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned offD[16];   // index dx*4 + dy
+    unsigned offD[NPIECE];   // index dx*PW + dy
 #pragma unroll
-    for (int dx = 0; dx < 4; ++dx)
+    for (int dx = 0; dx < PW; ++dx)
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy) {
-            const int hy = 4 * tg + 2 * tr + dy, hx = 2 * tc + dx;
-            const int P = (hx & 1) * G::HALF + hy * 9 + (hx >> 1);
-            offD[dx * 4 + dy] = lds0 + P * 64 + ((q ^ ((hx >> 1) & 3)) << 4);
+        for (int dy = 0; dy < PW; ++dy) {
+            if (UPS) {
+                const int hy = 2 * tg + tr + dy, hx = tc + dx;
+                offD[dx * PW + dy] = lds0 + (hy * 10 + hx) * 64 + ((q ^ (hx & 3)) << 4);
+            } else {
+                const int hy = 4 * tg + 2 * tr + dy, hx = 2 * tc + dx;
+                const int P = (hx & 1) * G::HALF + hy * 9 + (hx >> 1);
+                offD[dx * PW + dy] = lds0 + P * 64 + ((q ^ ((hx >> 1) & 3)) << 4);
+            }
         }
     const unsigned offU = lds0 + 2 * RAW_BYTES + nb0 * 1024 + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);
-    const unsigned offU1 = offU + WINO_U_BYTES;
+    const unsigned offU1 = offU + U_LDS;
 
-    f32x4 acc[16][NB];
-    // transformed input B^T d B of the current / next chunk (ping-pong); V[r][k] lives in element k*4 + r: the
-    // raw patch is read straight into the "next" array and both transform passes run in place
-    f32x4 va[16], vb[16];
-    auto col_pass = [](f32x4 (&d)[16], int dx) {       // d[dx*4 + dy] -> (B^T d)[r][dx] at d[dx*4 + r]
-        const f32x4 d0 = d[dx * 4 + 0], d1 = d[dx * 4 + 1], d2 = d[dx * 4 + 2], d3 = d[dx * 4 + 3];
-        d[dx * 4 + 0] = f4sub(d0, d2); d[dx * 4 + 1] = d1 + d2; d[dx * 4 + 2] = f4sub(d2, d1); d[dx * 4 + 3] = f4sub(d1, d3);
+    f32x4 acc[NP][NB];
+    // transformed input B^T d B of the current / next chunk (ping-pong); V[r][k] lives in element k*PW + r: the
+    // raw patch is read straight into the "next" array and both transform passes run in place.
+    // UPS = 0: B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]];  UPS = 1: B^T = [[0,1,0],[1,-1,0],[0,-1,1]]
+    f32x4 va[NPIECE], vb[NPIECE];
+    auto pass = [](f32x4& d0, f32x4& d1, f32x4& d2, f32x4& d3) {
+        const f32x4 a0 = d0, a1 = d1, a2 = d2, a3 = d3;
+        if (UPS) { d0 = a1; d1 = f4sub(a0, a1); d2 = f4sub(a2, a1); }
+        else { d0 = f4sub(a0, a2); d1 = a1 + a2; d2 = f4sub(a2, a1); d3 = f4sub(a1, a3); }
     };
-    auto row_pass = [](f32x4 (&d)[16], int r) {        // (B^T d)[r][.] -> V[r][k] at d[k*4 + r]
-        const f32x4 d0 = d[0 + r], d1 = d[4 + r], d2 = d[8 + r], d3 = d[12 + r];
-        d[0 + r] = f4sub(d0, d2); d[4 + r] = d1 + d2; d[8 + r] = f4sub(d2, d1); d[12 + r] = f4sub(d1, d3);
+    auto col_pass = [&](f32x4 (&d)[NPIECE], int dx) {   // d[dx*PW + dy] -> (B^T d)[r][dx] at d[dx*PW + r]
+        pass(d[dx * PW + 0], d[dx * PW + 1], d[dx * PW + 2], d[dx * PW + PW - 1]);
+    };
+    auto row_pass = [&](f32x4 (&d)[NPIECE], int r) {    // (B^T d)[r][.] -> V[r][k] at d[k*PW + r]
+        pass(d[0 * PW + r], d[1 * PW + r], d[2 * PW + r], d[(PW - 1) * PW + r]);
     };
 
     // One chunk: MFMAs of chunk c with V(c) = vcur, while the raw patch of chunk c+1 is read and
     // transformed into vnext.  Issue order per iteration i: U(i+2) x2, then (i<8) patch pieces 2i, 2i+1.
     // c is even in the first body of the unrolled chunk loop and odd in the second (PAR = c & 1), so the
     // buffer selection folds into the 16-bit immediate of every ds_read: no address arithmetic in the loop
-    auto chunk_body = [&](int c, auto par_c, f32x4 (&vcur)[16], f32x4 (&vnext)[16]) {
+    auto chunk_body = [&](int c, auto par_c, f32x4 (&vcur)[NPIECE], f32x4 (&vnext)[NPIECE]) {
         constexpr int PAR = decltype(par_c)::value;
         // U(c+1) goes to U buffer (c+1)&1 (last read in chunk c-1), raw(c+2) to raw buffer c&1 (its patch was read
         // in chunk c-1).  Past the end of the item the same slots carry the NEXT item's U(0), raw(0), raw(1) (nchunks
@@ -249,14 +271,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
         const bool en_u = own_u || have_nxt, en_r = own_r || have_nxt;
         const float* const ubase = own_u ? w_t : w_n;
         const float* const rbase = own_r ? in_t : in_n;
-        const int usoff = own_u ? (c + 1) * WINO_U_BYTES : 0;
+        const int usoff = own_u ? (c + 1) * U_BYTES : 0;
         const int rsoff = (own_r ? c + 2 : c + 2 - nchunks) * 64;
-        char* const udst = smem + 2 * RAW_BYTES + (1 - PAR) * WINO_U_BYTES;
+        char* const udst = smem + 2 * RAW_BYTES + (1 - PAR) * U_LDS;
         char* const rdst = smem + PAR * RAW_BYTES;
         if (ABL & 128) {   // microbench only: the MFMA stream alone (no LDS reads, no transform)
             f32x4 u01[2] = {vcur[0], vcur[1]};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 const f32x4 vv = vcur[i];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -264,59 +286,58 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
                     for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u01[nb][s], vv[s], acc[i][nb], 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) vnext[i] = vcur[i];
+            for (int i = 0; i < NPIECE; ++i) vnext[i] = vcur[i];
             return;
         }
         const unsigned ub = PAR ? offU1 : offU;
         constexpr int RB = (1 - PAR) * RAW_BYTES;    // raw buffer (c+1)&1
         f32x4 u[4][NB];      // U fragments in flight, slot = pos & 3
-        f32x4 (&d)[16] = vnext;   // raw patch of the next chunk, index dx*4 + dy; transformed in place
+        f32x4 (&d)[NPIECE] = vnext;   // raw patch of the next chunk, index dx*PW + dy; transformed in place
         u[0][0] = lds_rd128<0>(ub);                      // issue order = completion order: U(0) blocks, then U(1)
         if constexpr (NB == 2) u[0][NB - 1] = lds_rd128<1024>(ub);
         u[1][0] = lds_rd128<2048>(ub);
         if constexpr (NB == 2) u[1][NB - 1] = lds_rd128<2048 + 1024>(ub);
         static_for([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (i + 2 < 16) {
+            if constexpr (i + 2 < NP) {
                 u[(i + 2) & 3][0] = lds_rd128<(i + 2) * 2048>(ub);
                 if constexpr (NB == 2) u[(i + 2) & 3][NB - 1] = lds_rd128<(i + 2) * 2048 + 1024>(ub);
             }
-            if constexpr (i < 8) {
-                d[2 * i] = lds_rd128<RB>(offD[2 * i]);
-                d[2 * i + 1] = lds_rd128<RB>(offD[2 * i + 1]);
-            }
-            // U(i) is complete when at most wino_younger(i) younger reads are outstanding; in-order
-            // return also completes every patch piece issued before U(i), i.e. pieces < 2(i-2)
-            if constexpr (i >= 4 && i <= 10 && (i % 2) == 0) {
-                // column dx = (i-4)/2 of the patch (pieces 4dx..4dx+3, issued in iterations 2dx, 2dx+1) is complete
-                constexpr int dx = (i - 4) / 2;
-                lds_release4<wino_younger(i, NB)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
-            }
-            if constexpr (NB == 2) lds_release2<wino_younger(i, NB)>(u[i & 3][0], u[i & 3][1]);
-            else lds_release1<wino_younger(i, NB)>(u[i & 3][0]);
+            static_for([&](auto kc) {
+                constexpr int pc = i * G::PPI + decltype(kc)::value;
+                if constexpr (pc < NPIECE) d[pc] = lds_rd128<RB>(offD[pc]);
+            }, std::make_integer_sequence<int, G::PPI>{});
+            // U(i) is complete when at most younger(i) younger reads are outstanding; in-order return also
+            // completes every patch piece issued before U(i): those of iterations <= i-3
+            static_for([&](auto xc) {
+                constexpr int dx = decltype(xc)::value;
+                if constexpr (G::col_iter(dx) == i) {
+                    if constexpr (PW == 4) lds_release4<G::younger(i)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
+                    else lds_release3<G::younger(i)>(d[dx * 3 + 0], d[dx * 3 + 1], d[dx * 3 + 2]);
+                }
+            }, std::make_integer_sequence<int, PW>{});
+            if constexpr (NB == 2) lds_release2<G::younger(i)>(u[i & 3][0], u[i & 3][1]);
+            else lds_release1<G::younger(i)>(u[i & 3][0]);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
                 if constexpr (i < G::U_IT)
-                    bufld16_if(en_u, ubase, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
+                    bufld16_if(en_u && (i * NT + wave * 64 < G::U_PIECES), ubase, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
                 if constexpr (i < G::RAW_IT)
                     bufld16_if(en_r && (i * NT + wave * 64 < G::PIECES), rbase, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
             }
-            const f32x4 vv = vcur[(i & 3) * 4 + (i >> 2)];
+            const f32x4 vv = vcur[(i % PW) * PW + i / PW];
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3][nb][s], vv[s], acc[i][nb], 0, 0, 0);
             // input transform of the next chunk, sliced under the MFMAs
-            if constexpr (i >= 4 && i <= 10 && (i % 2) == 0) col_pass(d, (i - 4) / 2);
-            if constexpr (i >= 11 && i <= 14) {
-                constexpr int r = i - 11;
-                row_pass(d, r);
-                // V is first USED in the next chunk body, after the barrier: without this pin the compiler sinks the
-                // whole transform out of the MFMA shadow into the head of that block
-                if (WINO_PIN) asm volatile("" : "+v"(d[0 + r]), "+v"(d[4 + r]), "+v"(d[8 + r]), "+v"(d[12 + r]));
-            }
-        }, std::make_integer_sequence<int, 16>{});
+            static_for([&](auto xc) {
+                constexpr int k = decltype(xc)::value;
+                if constexpr (G::col_iter(k) == i) col_pass(d, k);
+                if constexpr (G::row_iter(k) == i) row_pass(d, k);
+            }, std::make_integer_sequence<int, PW>{});
+        }, std::make_integer_sequence<int, NP>{});
     };
 
     // ---- persistent loop over (pixel tile, cout slab) work items.  Only the first item has a prologue: the last
@@ -334,11 +355,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
         par_ntile = cur.nt;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) va[k] = *(const f32x4*)(smem + (offD[k] - lds0));
+        for (int k = 0; k < NPIECE; ++k) va[k] = *(const f32x4*)(smem + (offD[k] - lds0));
 #pragma unroll
-        for (int dx = 0; dx < 4; ++dx) col_pass(va, dx);
+        for (int dx = 0; dx < PW; ++dx) col_pass(va, dx);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) row_pass(va, r);
+        for (int r = 0; r < PW; ++r) row_pass(va, r);
     }
     while (have) {
         const int e_y0 = cur.ty * 16, e_x0 = cur.tx * 16, e_b = cur.b, e_ntile = cur.nt;
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
         in_n = in_of(nxt);
         w_n = w_of(nxt);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < NP; ++i)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (par_ntile != e_ntile) {            // (never re-staged when gridDim.x is a multiple of the slab count)
@@ -390,7 +411,19 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
         for (int nb = 0; nb < NB; ++nb) {
             const int co = e_ntile * 32 + (nb0 + nb) * 16 + 4 * q;
             f32x4 Y[2][2];
-            {
+            if constexpr (UPS) {   // A^T = [[1,1,0],[1,0,1]]
+                f32x4 T[2][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    T[0][c] = acc[0 + c][nb] + acc[3 + c][nb];
+                    T[1][c] = acc[0 + c][nb] + acc[6 + c][nb];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Y[i][0] = T[i][0] + T[i][1];
+                    Y[i][1] = T[i][0] + T[i][2];
+                }
+            } else {               // A^T = [[1,1,1,0],[0,1,-1,-1]]
                 f32x4 T[2][4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -451,14 +484,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
                         }
                     } else if (valid) {
                         if (ABL & 4) { if (o[0] == 123.456f) out_b[co] = o[0]; }
-                        else WINO_STORE((f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co), o);
+                        else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
                     }
                 }
             if (EPI & E_POOL) {
                 const int y2 = yb >> 1, x2 = xb >> 1;
                 if (y2 < Ho && x2 < Wo) {
                     if (ABL & 4) { if (pooled[0] == 123.456f) out_b[co] = pooled[0]; }
-                    else WINO_STORE((f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co), pooled);
+                    else *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
                 }
             }
         }
@@ -471,16 +504,18 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_k(const ConvP p) {
     }
 }
 
-// Weight transform U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], packed as
-// [Cout/32][Cin/CH][pos 16][32 couts][CH floats]; for CH=16 the 16-byte pieces are XOR-swizzled by (cout>>2)&3.
-__global__ void pack_wino_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin) {
+// Weight transform U = G g G^T, packed as [Cout/32][Cin/16][pos][32 couts][16 floats]; the 16-byte pieces are
+// XOR-swizzled by (cout>>2)&3.  ups = 0: G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (16 positions);
+// ups = 1: G = [[1,1,1],[1,0,0],[0,0,1]] (9 positions, the upsample-fused form above).
+__global__ void pack_wino_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int ups) {
     constexpr int CH = 16;
-    const size_t total = (size_t)Cout * Cin * 16;
+    const int np = ups ? 9 : 16, pw = ups ? 3 : 4;
+    const size_t total = (size_t)Cout * Cin * np;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
         const int cl = (int)(r % CH); r /= CH;            // stored channel slot inside the chunk
         const int j = r & 31; r >>= 5;
-        const int pos = r & 15; r >>= 4;
+        const int pos = (int)(r % np); r /= np;
         const int nchunks = Cin / CH;
         const int chunk = r % nchunks; r /= nchunks;
         const int n_tile = (int)r;
@@ -488,14 +523,14 @@ __global__ void pack_wino_k(const float* __restrict__ w, float* __restrict__ dst
         const int qq = qs ^ ((0 - (j >> 2)) & 3);     // XOR mask (0,3,2,1)[(j>>2)&3]: conflict-free ds_read_b128 of a 16-row fragment
         const int co = n_tile * 32 + j, ci = chunk * CH + qq * 4 + e;
         const float* g = w + ((size_t)co * Cin + ci) * 9;
-        const int pr = pos >> 2, pc = pos & 3;
+        const int pr = pos / pw, pc = pos % pw;
+        auto G3 = [&](int row, float g0, float g1, float g2) {
+            if (ups) return row == 0 ? g0 + g1 + g2 : (row == 1 ? g0 : g2);
+            return row == 0 ? g0 : (row == 1 ? 0.5f * (g0 + g1 + g2) : (row == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+        };
         float rowv[3];   // (G g)[pr][kx]
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const float g0 = g[0 * 3 + kx], g1 = g[1 * 3 + kx], g2 = g[2 * 3 + kx];
-            rowv[kx] = pr == 0 ? g0 : (pr == 1 ? 0.5f * (g0 + g1 + g2) : (pr == 2 ? 0.5f * (g0 - g1 + g2) : g2));
-        }
-        const float u = pc == 0 ? rowv[0] : (pc == 1 ? 0.5f * (rowv[0] + rowv[1] + rowv[2]) : (pc == 2 ? 0.5f * (rowv[0] - rowv[1] + rowv[2]) : rowv[2]));
-        dst[i] = u;
+        for (int kx = 0; kx < 3; ++kx) rowv[kx] = G3(pr, g[0 * 3 + kx], g[1 * 3 + kx], g[2 * 3 + kx]);
+        dst[i] = G3(pc, rowv[0], rowv[1], rowv[2]);
     }
 }

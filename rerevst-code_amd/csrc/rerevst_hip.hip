@@ -43,7 +43,7 @@ struct ConvW {           // one convolution's device weights
     float* raw = nullptr;    // OIHW as in the checkpoint
     float* pk = nullptr;     // kernel-native packed
     float* pk_wino = nullptr; // Winograd F(2x2,3x3) transformed pack for conv_wino_k
-    float* pk_ups = nullptr; // parity-folded pack for conv_ups2_k (convs that follow a nearest-x2 upsample)
+    float* pk_ups = nullptr; // upsample-fused transform pack (9 positions) for conv_wino_k<.., UPS = 1> (convs behind a nearest-x2 upsample)
     float* bias = nullptr;   // [Cout] (zeros for bias-free convs)
     int Cout = 0, Cin = 0, taps = 0, BN = 0;
 };
@@ -186,41 +186,35 @@ const ConvKey CONV_TABLE[] = {
     CK(32, 9, 0, 0), CK(128, 9, 0, 0),
 };
 
-template <int BN, int EPI>
-void ups2_launch(const ConvP& p, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_ups2_k<BN, EPI>), grid, dim3(256), 0, s, p);
-}
-#define UK(BN, EPI) {BN, 9, 1, EPI, &ups2_launch<BN, EPI>, "conv_ups2<" #BN "," #EPI ">"}
-const ConvKey UPS_TABLE[] = {UK(128, E_LRELU | E_NORM1), UK(64, E_LRELU | E_NORM1), UK(128, E_LRELU), UK(64, E_LRELU)};
-
 constexpr int WINO_NW = 8;     // waves per Winograd workgroup (conv_wino.h: 8 = two waves per SIMD, one 16-cout block each)
-template <int EPI>
+constexpr int UPW_NW = 4;      // upsample-fused form: 4 waves, 54 KB of LDS, two workgroups per CU
+template <int EPI, int NW, int UPS>
 void wino_launch(const ConvP& p, dim3 grid, hipStream_t s) {
+    using Geo = WinoGeo<NW, UPS>;
     static bool attr_set = false;     // >64 KB of dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, WINO_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<WINO_NW>::SMEM);
+        (void)hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino_k<EPI, 0, WINO_NW>), grid, dim3(WINO_NW * 64), WinoGeo<WINO_NW>::SMEM, s, p);
+    hipLaunchKernelGGL((conv_wino_k<EPI, 0, NW, UPS>), grid, dim3(NW * 64), Geo::SMEM, s, p);
 }
-#define WK(EPI) {32, 9, 0, EPI, &wino_launch<EPI>, "conv_wino<" #EPI ">"}
+#define WK(EPI) {32, 9, 0, EPI, &wino_launch<EPI, WINO_NW, 0>, "conv_wino<" #EPI ">"}
+#define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1>, "conv_upw<" #EPI ">"}
 const ConvKey WINO_TABLE[] = {
     WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
+    // ResidualBlock.conv1 behind the nearest-x2 upsample (forward pass / preparation pass)
+    UW(E_LRELU | E_NORM1), UW(E_LRELU),
 };
 
 int conv(rrv_handle h, const ConvCall& c) {
     const ConvW& w = *c.w;
     const ConvKey* k = nullptr;
     bool wino = false;
-    if (!c.ups && w.pk_wino) {      // every 3x3 layer with a Winograd pack runs conv_wino_k
+    if (c.ups ? w.pk_ups != nullptr : w.pk_wino != nullptr) {      // every 3x3 layer with a transform-domain pack runs conv_wino_k
         for (const ConvKey& e : WINO_TABLE)
-            if (e.EPI == c.epi) { k = &e; wino = true; break; }
+            if (e.EPI == c.epi && e.UPS == (int)c.ups) { k = &e; wino = true; break; }
     }
-    if (k) {
-    } else if (c.ups) {
-        for (const ConvKey& e : UPS_TABLE)
-            if (e.BN == w.BN && e.EPI == c.epi) { k = &e; break; }
-    } else {
+    if (!k && !c.ups) {
         for (const ConvKey& e : CONV_TABLE)
             if (e.BN == w.BN && e.TAPS == w.taps && e.EPI == c.epi) { k = &e; break; }
     }
@@ -233,7 +227,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W; p.Cin = w.Cin;
     p.out = c.out->p; p.H = c.H; p.W = c.W; p.Cout = w.Cout; p.B = c.B;
     p.in_bstride0 = 1;
-    p.wpk = wino ? w.pk_wino : (c.ups ? w.pk_ups : w.pk); p.bias = w.bias;
+    p.wpk = wino ? (c.ups ? w.pk_ups : w.pk_wino) : w.pk; p.bias = w.bias;
     if (!p.wpk) return fail(h, RRV_E_ARG, "conv: weights not packed for this kernel"); p.n1 = c.n1; p.n2 = c.n2; p.sty = c.sty;
     if (c.res) { p.res = c.res->p; p.Hr = c.res->H; p.Wr = c.res->W; }
     p.tiles_x = (c.W + 15) / 16; p.tiles_y = (c.H + 7) / 8;
@@ -242,20 +236,21 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (c.in->H != eh || c.in->W != ew) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
     if (c.out->H != oh || c.out->W != ow) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
-    if (c.ups || wino) { p.tiles_y = (c.H + 15) / 16; }
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B * (c.ups ? 2 : 1)), (unsigned)(w.Cout / w.BN));
-    if (wino) {   // persistent workgroups, one per CU, walking tiles_x*tiles_y*B*(Cout/32) work items
+    if (wino) { p.tiles_y = (c.H + 15) / 16; }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B), (unsigned)(w.Cout / w.BN));
+    if (wino) {   // persistent workgroups (one per CU; two for the upsample-fused form), walking tiles_x*tiles_y*B*(Cout/32) work items
         const unsigned slabs = (unsigned)(w.Cout / 32);
         const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B) * slabs;
-        grid = dim3(items < (unsigned)h->n_cus ? items : (unsigned)h->n_cus, 1);
+        const unsigned resident = (unsigned)h->n_cus * (c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);
+        grid = dim3(items < resident ? items : resident, 1);
         // slabs of one pixel tile on one XCD (workgroup w runs on XCD w % 8): the raw tile is fetched once per XCD group
         p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
     }
     const double px = (double)c.B * c.H * c.W;
     // algorithmic FLOPs = the reference's direct convolution (taps multiply-adds per output);
-    // executed: ups2 folds 9 taps into 4, Winograd F(2x2,3x3) needs 16 per 2x2 outputs (= 4 per pixel)
+    // executed: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 outputs (4 per pixel), the upsample-fused form 9 (2.25 per pixel)
     const double flops = 2.0 * px * w.Cout * w.Cin * w.taps;
-    const double flops_exec = 2.0 * px * w.Cout * w.Cin * ((c.ups || wino) ? 4 : w.taps);
+    const double flops_exec = 2.0 * px * w.Cout * w.Cin * (wino ? (c.ups ? 2.25 : 4.0) : (double)w.taps);
     const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * w.Cin + (double)c.B * oh * ow * w.Cout +
                                 (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps);
     hipStream_t s = h->stream;
@@ -292,15 +287,15 @@ int bn_for(int cout) { return cout >= 128 ? 128 : (cout >= 64 ? 64 : 32); }
 int pack_wino(rrv_handle h, ConvW& w) {
     const size_t total = (size_t)w.Cout * w.Cin * 16;
     if (!w.pk_wino) RCHK(dalloc(h, &w.pk_wino, total, false));
-    hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_wino, w.Cout, w.Cin);
+    hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_wino, w.Cout, w.Cin, 0);
     HIPCHK(hipGetLastError());
     return RRV_OK;
 }
 
 int pack_ups(rrv_handle h, ConvW& w) {
-    const size_t total = (size_t)w.Cout * w.Cin * 16;
+    const size_t total = (size_t)w.Cout * w.Cin * 9;
     if (!w.pk_ups) RCHK(dalloc(h, &w.pk_ups, total, false));
-    hipLaunchKernelGGL(pack_ups2_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_ups, w.Cout, w.Cin, w.BN);
+    hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_ups, w.Cout, w.Cin, 1);
     HIPCHK(hipGetLastError());
     return RRV_OK;
 }
