@@ -29,7 +29,7 @@ EPI_BITS = {"E_RELU": 1, "E_LRELU": 2, "E_NORM1": 4, "E_RES": 8, "E_RES_UPS": 16
 
 def rocprof_name(kernel):
     """bench kernel label -> the demangled name rocprofv3 reports, e.g.
-    'conv_wino<E_RELU | E_POOL>' -> 'void conv_wino_k<65, 0>(ConvP)'."""
+    'conv_wino<E_RELU | E_POOL>' -> 'void conv_wino_k<65, 0, 8, 0>(ConvP)'."""
     if "<" not in kernel:
         return kernel + "_k"
     base, args = kernel.split("<", 1)
@@ -37,11 +37,10 @@ def rocprof_name(kernel):
     def epi(txt):
         txt = txt.strip()
         return str(sum(EPI_BITS[t.strip()] for t in txt.split("|"))) if txt[:2] == "E_" else txt
-    if base == "conv_wino":
-        return "void conv_wino_k<%s, 0>(ConvP)" % epi(args)
-    if base == "conv_ups2":
-        bn, e = args.split(",", 1)
-        return "void conv_ups2_k<%s, %s>(ConvP)" % (bn.strip(), epi(e))
+    if base == "conv_wino":      # <EPI, ABL, waves, UPS>: rerevst_hip.hip WINO_NW / UPW_NW
+        return "void conv_wino_k<%s, 0, 8, 0>(ConvP)" % epi(args)
+    if base == "conv_upw":
+        return "void conv_wino_k<%s, 0, 4, 1>(ConvP)" % epi(args)
     if base == "conv_mfma":
         bn, taps, e = args.split(",", 2)
         return "void conv_mfma_k<%s, %s, %s, 0, 0, 1>(ConvP)" % (bn.strip(), taps.strip(), epi(e))
@@ -179,14 +178,14 @@ def main():
                              "gbs": round(a[3] / a[1] / 1e6, 1) if a[1] > 0 else None})
             dom = max(agg.items(), key=lambda kv: kv[1][1])
             achieved = dom[1][2] / dom[1][1] / 1e9
-            mf = [a for n, a in agg.items() if n.startswith(("conv_mfma", "conv_wino", "conv_ups2"))]
+            mf = [a for n, a in agg.items() if n.startswith(("conv_mfma", "conv_wino", "conv_upw"))]
             roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(dom[0]),
                     "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same "
                                       "command; bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024)",
                     "algorithmic_bytes_per_launch": round(dom[1][3] / dom[1][0]),
                     "note": "achieved = ALGORITHMIC FLOPs of the reference's direct 3x3 convolution / event time; the Winograd "
-                            "F(2x2,3x3) and upsample-folded kernels execute 2.25x fewer multiplies, so frac may exceed 1",
+                            "F(2x2,3x3) kernels execute 2.25x and the upsample-fused ones 4x fewer multiplies, so frac may exceed 1",
                     "executed_tflops": round(dom[1][4] / dom[1][1] / 1e9, 2),
                     "executed_frac_of_mfma_peak": round(dom[1][4] / dom[1][1] / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(dom[1][1] / dom[1][0], 5), "share_of_gpu_time": round(dom[1][1] / tot_ms, 3),

@@ -5,7 +5,7 @@
 // down/up convs :181-187; ResidualBlock conv1/conv2/conv_shortcut :103-105) together with
 // the pointwise ops the reference runs as separate eager kernels after them: bias,
 // ReLU / LeakyReLU(0.2), MaxPool2d(2) (vgg cfg), F.interpolate(nearest, x2) in front of
-// the conv (:113, conv_ups2_k), saved-statistics InstanceNorm.forward (:43-57), the residual adds
+// the conv (:113, conv_wino_k<.., UPS = 1> in conv_wino.h), saved-statistics InstanceNorm.forward (:43-57), the residual adds
 // (:122, :217) and the AdaIN affine (:357-364).
 //
 // Data layout (HBM): activations are NHWC fp32 with a one-pixel ZERO ring:
@@ -46,7 +46,7 @@ enum {
 };
 
 struct ConvP {
-    const float* in;   // input tensor (ring layout); dims Hi,Wi (half of H,W for conv_ups2_k)
+    const float* in;   // input tensor (ring layout); dims Hi,Wi (half of H,W for the upsample-fused conv_wino_k)
     int Hi, Wi, Cin;
     float* out;        // output tensor (ring layout); dims H,W (H/2,W/2 when E_POOL)
     int H, W, Cout;    // convolution resolution and output channels
@@ -318,160 +318,6 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
             long long* dbg = (long long*)p.n1;   // microbench passes a debug buffer here
             const int wg = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
             dbg[wg * 4 + 0] = t_start; dbg[wg * 4 + 1] = t_loop; dbg[wg * 4 + 2] = t_issued; dbg[wg * 4 + 3] = t_end;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// conv_ups2_k — conv3x3 applied to a nearest-x2 upsampled tensor (ResidualBlock.conv1 after
-// F.interpolate, test/style_network_global.py:113,116), evaluated on the LOW-resolution input.
-//
-// For an output pixel of parity (py,px) the nine taps of the upsampled image land on only
-// 2x2 distinct low-res pixels, so the layer is four parity-specific 2x2 convolutions whose
-// weights are sums of the original taps (rows: py=0 -> {ky0 | ky1+ky2}, py=1 -> {ky0+ky1 | ky2};
-// same for columns; pre-summed once at weight-pack time).  4 taps instead of 9: 2.25x fewer
-// FLOPs, and the upsampled tensor is never materialised.
-//
-// A workgroup owns a 16x16 high-res tile and ONE row parity py: M-subtiles are
-// (px, row-half) blocks of 4x8 low-res positions, so the two M-subtiles of a wave share their
-// weight fragments.  Per (16-channel chunk, tap) step it stages the weights of both column
-// parities (2 x BN x 16) next to the 10x10 low-res halo tile.
-template <int BN, int EPI>
-__global__ __launch_bounds__(256) void conv_ups2_k(const ConvP p) {
-    using WC = WaveCfg<BN>;
-    static_assert(WC::WAVES_M == 2 && WC::WM_SUB == 2, "ups2 needs the 2x2 wave layout");
-    constexpr int HWD = 10, NPIX = 100;
-    constexpr int A_ITERS = 2, A_BYTES = A_ITERS * 256 * 16;
-    constexpr int B_ITERS = (2 * BN * 4) / 256;
-    constexpr int B_BYTES = 2 * BN * 64;
-    __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + 2 * B_BYTES];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: LDS-DMA bases in SGPRs
-    const int lane = tid & 63, h = lane >> 5, l31 = lane & 31;
-    const int px = wave % 2, wave_n = wave / 2;
-
-    int bx = blockIdx.x;
-    const int py = bx & 1;
-    bx >>= 1;
-    const int tx = bx % p.tiles_x;
-    bx /= p.tiles_x;
-    const int ty = bx % p.tiles_y;
-    const int b = bx / p.tiles_y;
-    const int n_tile = blockIdx.y;
-    const int y0 = ty * 16, x0 = tx * 16;
-    const int nchunks = p.Cin >> 4;
-
-    const float* in_b = p.in + (size_t)b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
-    const int ys = (y0 >> 1) - 1, xs = (x0 >> 1) - 1;
-    int asrc[A_ITERS];
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-        const int e = it * 256 + tid;
-        int pp = e >> 2;
-        const int qq = e & 3;
-        if (pp >= NPIX) pp = 0;
-        const int hy = pp / HWD, hx = pp - hy * HWD;
-        asrc[it] = ((ys + hy + 1) * (p.Wi + 2) + (xs + hx + 1)) * p.Cin + 4 * (qq ^ ((pp >> 2) & 3));
-    }
-    const float* w_tile = p.wpk + (size_t)n_tile * nchunks * 16 * (BN * 16);
-
-    auto stage = [&](int chunk, int tap, int step) {
-        char* bdst = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
-#pragma unroll
-        for (int it = 0; it < B_ITERS; ++it)
-            bufld16(w_tile, bdst + (it * 256 + wave * 64) * 16, tid * 16, ((chunk * 2 + py) * 4 + tap) * (2 * BN * 64) + it * 4096);
-        if (tap == 0) {
-            char* adst = smem + (chunk & 1) * A_BYTES;
-#pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) bufld16(in_b, adst + (it * 256 + wave * 64) * 16, asrc[it] * 4, chunk * 64);
-        }
-    };
-
-    const int r_ = l31 >> 3, c_ = l31 & 7;
-    int offB[WC::WN_SUB][2];
-#pragma unroll
-    for (int ns = 0; ns < WC::WN_SUB; ++ns) {
-        const int jj = px * BN + (wave_n * WC::WN_SUB + ns) * 32 + l31;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) offB[ns][g] = jj * 64 + ((((2 * g + h) ^ ((jj >> 2) & 3))) << 4);
-    }
-
-    f32x16 acc[2][WC::WN_SUB];
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-        for (int ns = 0; ns < WC::WN_SUB; ++ns)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
-
-    stage(0, 0, 0);
-    int step = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const char* abuf = smem + (chunk & 1) * A_BYTES;
-#pragma unroll
-        for (int tap = 0; tap < 4; ++tap, ++step) {
-            __syncthreads();
-            if (tap + 1 < 4)
-                stage(chunk, tap + 1, step + 1);
-            else if (chunk + 1 < nchunks)
-                stage(chunk + 1, 0, step + 1);
-            const char* bbuf = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
-            const int dy = tap >> 1, dx = tap & 1;
-            int offA[2];
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms) {
-                const int pp = (ms * 4 + r_ + dy + py) * HWD + (c_ + dx + px);
-                offA[ms] = pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);
-            }
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                f32x4 a[2], bb[WC::WN_SUB];
-#pragma unroll
-                for (int ms = 0; ms < 2; ++ms) a[ms] = *(const f32x4*)(abuf + (offA[ms] ^ (g << 5)));
-#pragma unroll
-                for (int ns = 0; ns < WC::WN_SUB; ++ns) bb[ns] = *(const f32x4*)(bbuf + offB[ns][g]);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-                        for (int ns = 0; ns < WC::WN_SUB; ++ns)
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[ns][s], a[ms][s], acc[ms][ns], 0, 0, 0);
-            }
-        }
-    }
-
-    // lane = low-res position (r_, c_) of its (px, row-half) block; registers = 16 output channels
-    float* out_b = p.out + (size_t)b * (size_t)(p.H + 2) * (p.W + 2) * p.Cout;
-#pragma unroll
-    for (int ns = 0; ns < WC::WN_SUB; ++ns) {
-#pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int co = n_tile * BN + (wave_n * WC::WN_SUB + ns) * 32 + 8 * cg + 4 * h;
-            const f32x4 bias = *(const f32x4*)(p.bias + co);
-            f32x4 m1, r1, lo1, hi1;
-            if (EPI & E_NORM1) {
-                m1 = *(const f32x4*)(p.n1 + co); r1 = *(const f32x4*)(p.n1 + p.Cout + co);
-                lo1 = *(const f32x4*)(p.n1 + 2 * p.Cout + co); hi1 = *(const f32x4*)(p.n1 + 3 * p.Cout + co);
-            }
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms) {
-                const int y = y0 + 2 * (ms * 4 + r_) + py, x = x0 + 2 * c_ + px;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[ms][ns][4 * cg + e] + bias[e];
-                    if (EPI & E_RELU) t = fmaxf(t, 0.f);
-                    if (EPI & E_LRELU) t = (t >= 0.f) ? t : t * 0.2f;
-                    if (EPI & E_NORM1) {
-                        t = (t - m1[e]) * r1[e];
-                        t = fminf(hi1[e], fmaxf(lo1[e], t));
-                    }
-                    v[e] = t;
-                }
-                if (y < p.H && x < p.W) *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = v;
-            }
         }
     }
 }

@@ -41,7 +41,7 @@
 //     y[2i]   = g0 x[i-1] + (g1+g2) x[i]   = s x[i] + g0 (x[i-1] - x[i])
 //     y[2i+1] = (g0+g1) x[i] + g2 x[i+1]   = s x[i] + g2 (x[i+1] - x[i]),     s = g0+g1+g2
 //   i.e. 3 multiplies per 2 outputs: 9 positions per 2x2 outputs in 2-D (36 for the direct form, 16 for the
-//   parity-folded conv_ups2_k), 3x3 patches one pixel apart, 10x10 low-resolution halo, all coefficients +-1.
+//   a parity-folded 2x2 conv), 3x3 patches one pixel apart, 10x10 low-resolution halo, all coefficients +-1.
 template <int NW, int UPS>
 struct WinoGeo {
     static constexpr int NT = NW * 64;                       // threads

@@ -27,35 +27,6 @@ __global__ void pack_conv_k(const float* __restrict__ w, float* __restrict__ dst
     }
 }
 
-// conv_ups2_k weights: OIHW 3x3 -> parity-folded 2x2 taps,
-// [Cout/BN][Cin/16][py][tap=dy*2+dx][px][BN][16 floats swizzled].
-// Row taps: py=0: dy0={ky0}, dy1={ky1,ky2}; py=1: dy0={ky0,ky1}, dy1={ky2} (same for columns).
-__global__ void pack_ups2_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int BN) {
-    const size_t total = (size_t)Cout * Cin * 16;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t r = i;
-        const int e = r & 3; r >>= 2;
-        const int qs = r & 3; r >>= 2;
-        const int j = r % BN; r /= BN;
-        const int px = r & 1; r >>= 1;
-        const int tap = r & 3; r >>= 2;
-        const int py = r & 1; r >>= 1;
-        const int nchunks = Cin >> 4;
-        const int chunk = r % nchunks; r /= nchunks;
-        const int n_tile = (int)r;
-        const int q = qs ^ ((j >> 2) & 3);
-        const int co = n_tile * BN + j, ci = chunk * 16 + q * 4 + e;
-        const int dy = tap >> 1, dx = tap & 1;
-        const int ky0 = py ? (dy ? 2 : 0) : (dy ? 1 : 0), ky1 = py ? (dy ? 2 : 1) : (dy ? 2 : 0);
-        const int kx0 = px ? (dx ? 2 : 0) : (dx ? 1 : 0), kx1 = px ? (dx ? 2 : 1) : (dx ? 2 : 0);
-        const float* wp = w + ((size_t)co * Cin + ci) * 9;
-        float s = 0.f;
-        for (int ky = ky0; ky <= ky1; ++ky)
-            for (int kx = kx0; kx <= kx1; ++kx) s += wp[ky * 3 + kx];
-        dst[i] = s;
-    }
-}
-
 // conv_first weights: OIHW [64][3][3][3] -> [27][64] rows (ky*3+kx)*3 + c
 __global__ void pack_first_k(const float* __restrict__ w, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
