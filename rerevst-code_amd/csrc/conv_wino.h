@@ -111,6 +111,14 @@ __device__ __forceinline__ f32x4 f4sub(const f32x4 a, const f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+__device__ __forceinline__ f32x4 f4add(const f32x4 a, const f32x4 b) {   // (the compiler picks four v_add_f32 here)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
     auto pass = [](f32x4& d0, f32x4& d1, f32x4& d2, f32x4& d3) {
         const f32x4 a0 = d0, a1 = d1, a2 = d2, a3 = d3;
         if (UPS) { d0 = a1; d1 = f4sub(a0, a1); d2 = f4sub(a2, a1); }
-        else { d0 = f4sub(a0, a2); d1 = a1 + a2; d2 = f4sub(a2, a1); d3 = f4sub(a1, a3); }
+        else { d0 = f4sub(a0, a2); d1 = f4add(a1, a2); d2 = f4sub(a2, a1); d3 = f4sub(a1, a3); }
     };
     auto col_pass = [&](f32x4 (&d)[NPIECE], int dx) {   // d[dx*PW + dy] -> (B^T d)[r][dx] at d[dx*PW + r]
         pass(d[dx * PW + 0], d[dx * PW + 1], d[dx * PW + 2], d[dx * PW + PW - 1]);
