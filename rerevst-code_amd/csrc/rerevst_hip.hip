@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <thread>
 #include <stdio.h>
 #include <map>
 #include <string>
@@ -102,6 +103,10 @@ struct rrv_ctx {
     int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
     float* d_outf = nullptr; size_t d_outf_cap = 0;
+    // host-buffer entry: two staging sets (pinned host + device, input and output) so that H2D / kernels / D2H /
+    // the copies from and to the caller's pageable arrays of consecutive sub-batches overlap
+    struct HostStage { uint8_t* pin_in = nullptr; float* pin_out = nullptr; uint8_t* d_in = nullptr; float* d_out = nullptr;
+                       size_t cap = 0; hipEvent_t done = nullptr; } hstage[2];
     int n_cus = 256;
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -659,6 +664,13 @@ int rrv_destroy(rrv_handle h) {
     for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->d_outf) (void)hipFree(h->d_outf);
+    for (auto& st : h->hstage) {
+        if (st.pin_in) (void)hipHostFree(st.pin_in);
+        if (st.pin_out) (void)hipHostFree(st.pin_out);
+        if (st.d_in) (void)hipFree(st.d_in);
+        if (st.d_out) (void)hipFree(st.d_out);
+        if (st.done) (void)hipEventDestroy(st.done);
+    }
     for (ProfEntry& e : h->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     for (int i = 0; i < RRV_MAX_SLOTS; ++i) (void)hipStreamDestroy(h->streams[i]);
     delete h;
@@ -910,12 +922,80 @@ static int host_roundtrip(rrv_handle h, const uint8_t* frames, int B, int H, int
     return RRV_OK;
 }
 
+// B frames in sub-batches of up to 8 through the two staging sets: while sub-batch k runs on its stream, k+1 is
+// copied in and k-1 is copied back to the caller's array.
+constexpr int HOST_SUB = 8;
+// copies between the caller's pageable arrays and the pinned staging buffers: first-touch page faults of a fresh
+// output array make a single thread slower than the GPU, so large copies are split over a few threads
+static void host_copy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t MIN_SLICE = (size_t)2 << 20;
+    int nt = (int)(bytes / MIN_SLICE);
+    if (nt > 4) nt = 4;
+    if (nt < 2) { memcpy(dst, src, bytes); return; }
+    const size_t slice = ((bytes / nt) + 4095) & ~(size_t)4095;
+    std::thread th[3];
+    for (int t = 1; t < nt; ++t) {
+        const size_t o = (size_t)t * slice, n = o >= bytes ? 0 : (bytes - o < slice ? bytes - o : slice);
+        th[t - 1] = std::thread([=] { if (n) memcpy((char*)dst + o, (const char*)src + o, n); });
+    }
+    memcpy(dst, src, slice < bytes ? slice : bytes);
+    for (int t = 1; t < nt; ++t) th[t - 1].join();
+}
+static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out) {
+    if (!h || !frames || !out || B < 1) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t fb = (size_t)H * W * 3;
+    const int sub = B < HOST_SUB ? B : HOST_SUB;
+    RCHK(sync_all(h));
+    for (auto& st : h->hstage) {
+        if (st.cap >= (size_t)sub * fb) continue;
+        if (st.pin_in) (void)hipHostFree(st.pin_in);
+        if (st.pin_out) (void)hipHostFree(st.pin_out);
+        if (st.d_in) (void)hipFree(st.d_in);
+        if (st.d_out) (void)hipFree(st.d_out);
+        st.pin_in = nullptr; st.pin_out = nullptr; st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
+        HIPCHK(hipHostMalloc((void**)&st.pin_in, (size_t)sub * fb, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&st.pin_out, (size_t)sub * fb * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void**)&st.d_in, (size_t)sub * fb));
+        HIPCHK(hipMalloc((void**)&st.d_out, (size_t)sub * fb * sizeof(float)));
+        if (!st.done) HIPCHK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+        st.cap = (size_t)sub * fb;
+    }
+    const int nchunk = (B + sub - 1) / sub;
+    auto count = [&](int k) { return (k + 1) * sub <= B ? sub : B - k * sub; };
+    auto drain = [&](int k) -> int {       // sub-batch k back to the caller
+        auto& st = h->hstage[k & 1];
+        HIPCHK(hipEventSynchronize(st.done));
+        host_copy(out + (size_t)k * sub * fb, st.pin_out, (size_t)count(k) * fb * sizeof(float));
+        return RRV_OK;
+    };
+    int rc = RRV_OK;
+    for (int k = 0; k < nchunk && rc == RRV_OK; ++k) {
+        auto& st = h->hstage[k & 1];
+        if (k >= 2) rc = drain(k - 2);
+        if (rc != RRV_OK) break;
+        const int nb = count(k);
+        host_copy(st.pin_in, frames + (size_t)k * sub * fb, (size_t)nb * fb);
+        h->next_slot = (k & 1) % h->n_slots;
+        hipStream_t sm = h->streams[h->profiling ? 0 : h->next_slot];
+        HIPCHK(hipMemcpyAsync(st.d_in, st.pin_in, (size_t)nb * fb, hipMemcpyHostToDevice, sm));
+        rc = rrv_transfer_batch_device(h, st.d_in, nb, H, W, st.d_out);
+        if (rc != RRV_OK) break;
+        HIPCHK(hipMemcpyAsync(st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, sm));
+        HIPCHK(hipEventRecord(st.done, sm));
+    }
+    if (rc != RRV_OK) { (void)sync_all(h); h->next_slot = 0; return rc; }
+    for (int k = nchunk - 2 < 0 ? 0 : nchunk - 2; k < nchunk; ++k) RCHK(drain(k));
+    h->next_slot = 0;
+    return RRV_OK;
+}
+
 int rrv_transfer(rrv_handle h, const uint8_t* frame, int H, int W, float* out) {
-    return host_roundtrip(h, frame, 1, H, W, out, nullptr, 0);
+    return host_pipeline(h, frame, 1, H, W, out);
 }
 
 int rrv_transfer_batch(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out) {
-    return host_roundtrip(h, frames, B, H, W, out, nullptr, 0);
+    return host_pipeline(h, frames, B, H, W, out);
 }
 
 int rrv_transfer_blend(rrv_handle h, const uint8_t* frame, int H, int W, const float* wts, int ns, float* out) {

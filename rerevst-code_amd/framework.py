@@ -127,11 +127,19 @@ class Stylization():
         """[B][H][W][3] uint8 in HBM -> [B][H][W][3] float32 in HBM, asynchronous on the library stream."""
         self._chk(self._lib.rrv_transfer_batch_device(self._h, C.c_void_p(d_in_ptr), B, H, W, C.c_void_p(d_out_ptr)))
 
-    def transfer_batch(self, frames):
-        """Stylize a list of equally sized uint8 BGR frames in one launch sequence."""
-        a = np.stack([_u8_image(f, "frame") for f in frames])
+    def transfer_batch(self, frames, out=None):
+        """Stylize equally sized uint8 BGR frames (a list, or one [B][H][W][3] array) in one call; sub-batches are
+        pipelined inside the library (copy in / kernels / copy out).  `out`: optional float32 [B][H][W][3] array to
+        fill instead of allocating a fresh one."""
+        if isinstance(frames, np.ndarray) and frames.ndim == 4 and frames.dtype == np.uint8 and frames.shape[3] == 3:
+            a = np.ascontiguousarray(frames)
+        else:
+            a = np.stack([_u8_image(f, "frame") for f in frames])
         B, H, W, _ = a.shape
-        out = np.empty((B, H, W, 3), dtype=np.float32)
+        if out is None:
+            out = np.empty((B, H, W, 3), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (B, H, W, 3) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape %r" % ((B, H, W, 3),))
         self._chk(self._lib.rrv_transfer_batch(self._h, a.ctypes.data_as(C.c_void_p), B, H, W, out.ctypes.data_as(C.c_void_p)))
         return out
 

@@ -47,7 +47,7 @@ def shard_range(frame_num, rank, world):
     return lo, hi
 
 
-def stylize_video(model, frames, style, rank=0, world=1, broadcast=None, interval=8):
+def stylize_video(model, frames, style, rank=0, world=1, broadcast=None, interval=8, chunk=32):
     """generate_real_video.py main flow on one rank of `world`.
 
     `frames`: list of uint8 BGR HWC arrays (the whole video; only the sampled frames and
@@ -72,8 +72,14 @@ def stylize_video(model, frames, style, rank=0, world=1, broadcast=None, interva
     tool = ReshapeTool()
     lo, hi = shard_range(n, rank, world)
     out = {}
-    for i in range(lo, hi):
-        H, W, _ = frames[i].shape
-        styled = model.transfer(tool.process(frames[i]))
-        out[i] = styled[64:64 + H, 64:64 + W, :]
+    # the host-buffer batch entry pipelines sub-batches (copy in / kernels / copy out) inside one call
+    batch = getattr(model, "transfer_batch", None)     # a model with only the reference's per-frame transfer() works too
+    if batch is None:
+        batch = lambda fs: np.stack([model.transfer(f) for f in fs])
+    for c0 in range(lo, hi, chunk):
+        idx = list(range(c0, min(hi, c0 + chunk)))
+        styled = batch([tool.process(frames[i]) for i in idx])
+        for j, i in enumerate(idx):
+            H, W, _ = frames[i].shape
+            out[i] = styled[j, 64:64 + H, 64:64 + W, :]
     return out

@@ -13,7 +13,16 @@ t = time.perf_counter(); n = 40
 for i in range(n): s.transfer(frames[i % 8])
 dt = time.perf_counter() - t
 print("host entry, 1 frame per call: %.1f frames/s (%.3f ms/frame)" % (n / dt, 1e3 * dt / n))
-t = time.perf_counter()
-for i in range(5): s.transfer_batch(frames)
-dt = time.perf_counter() - t
-print("host entry, 8 frames per call: %.1f frames/s (%.3f ms/frame)" % (40 / dt, 1e3 * dt / 40))
+for nb in (8, 32, 64):
+    batch = [frames[i % 8] for i in range(nb)]
+    s.transfer_batch(batch)
+    reps = max(1, 128 // nb)
+    t = time.perf_counter()
+    for i in range(reps): s.transfer_batch(batch)
+    dt = time.perf_counter() - t
+    print("host entry, %d frames per call: %.1f frames/s (%.3f ms/frame)" % (nb, reps * nb / dt, 1e3 * dt / (reps * nb)))
+    arr = np.stack(batch); out = np.empty(arr.shape, np.float32); s.transfer_batch(arr, out=out)
+    t = time.perf_counter()
+    for i in range(reps): s.transfer_batch(arr, out=out)
+    dt = time.perf_counter() - t
+    print("   same, stacked input array and reused output array: %.1f frames/s" % (reps * nb / dt))
