@@ -71,6 +71,25 @@ def test_batched_transfer_equals_per_frame(hip, pkg, oracle):
         np.testing.assert_array_equal(batch[k], single[k])
 
 
+def test_host_batch_pipeline_ragged_count(hip, pkg, oracle):
+    """19 frames through the host-buffer batch entry (pinned double staging: sub-batches of 8, 8 and 3 on alternating
+    streams) == 19 per-frame transfers; stacked-array input and caller-provided output buffer included."""
+    g = load_golden("global_a")
+    hip.set_state(g["state"])
+    frames = [oracle.reflect_pad(pkg.synth_frame(100 + i, 40, 56, kind="smooth"), 128, 128) for i in range(19)]
+    single = [hip.transfer(f) for f in frames]
+    batch = hip.transfer_batch(frames)
+    assert batch.shape == (19, 128, 128, 3)
+    for k in range(19):
+        np.testing.assert_array_equal(batch[k], single[k])
+    out = np.full((19, 128, 128, 3), -1.0, np.float32)
+    ret = hip.transfer_batch(np.stack(frames), out=out)
+    assert ret is out
+    np.testing.assert_array_equal(out, batch)
+    with pytest.raises(ValueError):
+        hip.transfer_batch(frames, out=np.empty((3, 128, 128, 3), np.float32))
+
+
 def test_multistyle_blend_matches_reference(pkg, weights, oracle):
     """Config-5 path: two styles prepared, per-style state, blended transfer (weights .3/.7)."""
     g = load_golden("multistyle_s2")
