@@ -185,8 +185,6 @@ struct ConvKey { int BN, TAPS, UPS, EPI; ConvFn fn; const char* name; };
 const ConvKey CONV_TABLE[] = {
     // 1x1 shortcuts of the residual blocks (evaluated before the upsample)
     CK(128, 1, 0, 0), CK(64, 1, 0, 0),
-    // KernelFilter 32->512 convs with the folded dynamic filter (+ residual, + AdaIN after Filter3)
-    CK(128, 9, 0, E_RES), CK(128, 9, 0, E_RES | E_NORM2),
     // preparation pass: FilterPredictor 512->32 convs and the 32->512 conv of frame 0 (raw outputs)
     CK(32, 9, 0, 0), CK(128, 9, 0, 0),
 };
@@ -207,6 +205,8 @@ void wino_launch(const ConvP& p, dim3 grid, hipStream_t s) {
 #define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1>, "conv_upw<" #EPI ">"}
 const ConvKey WINO_TABLE[] = {
     WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
+    // KernelFilter 32->512 convs with the folded dynamic filter (+ residual, + AdaIN after Filter3)
+    WK(E_RES), WK(E_RES | E_NORM2),
     // ResidualBlock.conv1 behind the nearest-x2 upsample (forward pass / preparation pass)
     UW(E_LRELU | E_NORM1), UW(E_LRELU),
 };
@@ -377,6 +377,7 @@ int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
     hipLaunchKernelGGL(fold_up_k, dim3((512 * 32 * 9 + 255) / 256), dim3(256), 0, h->stream, F2, (const float*)wu.raw, fu.raw, 512);
     HIPCHK(hipGetLastError());
     RCHK(pack(h, fu));
+    RCHK(pack_wino(h, fu));          // 32 input channels = two 16-channel chunks per work item
     return RRV_OK;
 }
 
