@@ -268,8 +268,9 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
     // transformed into vnext.  Issue order per iteration i: U(i+2) x2, then (i<8) patch pieces 2i, 2i+1.
     // c is even in the first body of the unrolled chunk loop and odd in the second (PAR = c & 1), so the
     // buffer selection folds into the 16-bit immediate of every ds_read: no address arithmetic in the loop
-    auto chunk_body = [&](int c, auto par_c, f32x4 (&vcur)[NPIECE], f32x4 (&vnext)[NPIECE]) {
+    auto chunk_body = [&](int c, auto par_c, auto first_c, f32x4 (&vcur)[NPIECE], f32x4 (&vnext)[NPIECE]) {
         constexpr int PAR = decltype(par_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;    // first chunk of an item: accumulators start from zero
         // U(c+1) goes to U buffer (c+1)&1 (last read in chunk c-1), raw(c+2) to raw buffer c&1 (its patch was read
         // in chunk c-1).  Past the end of the item the same slots carry the NEXT item's U(0), raw(0), raw(1) (nchunks
         // is even, so the buffer parities line up): the K loops of consecutive items form one stream.  The LDS-DMA
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u01[nb][s], vv[s], acc[i][nb], 0, 0, 0);
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u01[nb][s], vv[s], (FIRST && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][nb], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) vnext[i] = vcur[i];
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3][nb][s], vv[s], acc[i][nb], 0, 0, 0);
+                    acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i & 3][nb][s], vv[s], (FIRST && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][nb], 0, 0, 0);
             // input transform of the next chunk, sliced under the MFMAs
             static_for([&](auto xc) {
                 constexpr int k = decltype(xc)::value;
@@ -375,20 +377,20 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
         have_nxt = nxt.b < p.B;
         in_n = in_of(nxt);
         w_n = w_of(nxt);
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (par_ntile != e_ntile) {            // (never re-staged when gridDim.x is a multiple of the slab count)
             __syncthreads();                       // slower waves may still read the old slab's parameters
             stage_params(e_ntile);                 // lands before the first K-loop barrier
             par_ntile = e_ntile;
         }
         tick(0);                              // zero acc (+ previous epilogue tail)
-        for (int c = 0; c < nchunks; c += 2) {
-            chunk_body(c, std::integral_constant<int, 0>{}, va, vb);
-            if (!(ABL & 2)) __syncthreads();      // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
-            chunk_body(c + 1, std::integral_constant<int, 1>{}, vb, va);
+        chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb);
+        if (!(ABL & 2)) __syncthreads();          // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
+        chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
+        if (!(ABL & 2)) __syncthreads();
+        for (int c = 2; c < nchunks; c += 2) {
+            chunk_body(c, std::integral_constant<int, 0>{}, std::false_type{}, va, vb);
+            if (!(ABL & 2)) __syncthreads();
+            chunk_body(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
             if (!(ABL & 2)) __syncthreads();
         }
         tick(3);                              // K loop
