@@ -14,6 +14,7 @@
 #include "../../include/rerevst_hip.h"
 #include "conv_mfma.h"
 #include "conv_wino.h"
+#include "conv_wino_split.h"
 #include "conv_thin.h"
 #include "prep_kernels.h"
 
@@ -201,7 +202,16 @@ void wino_launch(const ConvP& p, dim3 grid, hipStream_t s) {
     }
     hipLaunchKernelGGL((conv_wino_k<EPI, 0, NW, UPS>), grid, dim3(NW * 64), Geo::SMEM, s, p);
 }
-#define WK(EPI) {32, 9, 0, EPI, &wino_launch<EPI, WINO_NW, 0>, "conv_wino<" #EPI ">"}
+template <int EPI>
+void wsplit_launch(const ConvP& p, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wino_split_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wino_split_k<EPI>), grid, dim3(512), WSPLIT_SMEM_BYTES, s, p);
+}
+#define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI>, "conv_wino<" #EPI ">"}
 #define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1>, "conv_upw<" #EPI ">"}
 const ConvKey WINO_TABLE[] = {
     WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),

@@ -7,6 +7,7 @@
 #include <vector>
 #include "../rerevst-code_amd/csrc/conv_mfma.h"
 #include "../rerevst-code_amd/csrc/conv_wino.h"
+#include "../rerevst-code_amd/csrc/conv_wino_split.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int NW, int UPS = 1>
@@ -39,13 +40,18 @@ int check(int B, int Hl, int Wl, int Cin, int Cout, int tap = -1) {
     ConvP p{};
     p.in = in; p.Hi = Hl; p.Wi = Wl; p.Cin = Cin; p.out = out; p.H = H; p.W = W; p.Cout = Cout; p.B = B; p.in_bstride0 = 1;
     p.wpk = wp; p.bias = bias; p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 15) / 16;
-    using Geo = WinoGeo<NW, UPS>;
+    using Geo = WinoGeo<NW == 9 ? 8 : NW, UPS>;
     const int items = p.tiles_x * p.tiles_y * B * (Cout / 32);
     const int resident = 256 * Geo::OCC;
     dim3 grid(items < resident ? items : resident, 1);
     p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % (Cout / 32) == 0) ? 1 : 0;
-    CK(hipFuncSetAttribute((const void*)conv_wino_k<E_LRELU, 0, NW, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM));
-    hipLaunchKernelGGL((conv_wino_k<E_LRELU, 0, NW, UPS>), grid, dim3(NW * 64), Geo::SMEM, 0, p);
+    if (NW == 9) {      // the row-split 8-wave kernel
+        CK(hipFuncSetAttribute((const void*)conv_wino_split_k<E_LRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES));
+        hipLaunchKernelGGL((conv_wino_split_k<E_LRELU>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, p);
+    } else {
+        CK(hipFuncSetAttribute((const void*)conv_wino_k<E_LRELU, 0, NW == 9 ? 8 : NW, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM));
+        hipLaunchKernelGGL((conv_wino_k<E_LRELU, 0, NW == 9 ? 8 : NW, UPS>), grid, dim3(NW * 64), Geo::SMEM, 0, p);
+    }
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(got.data(), out, out_f * 4, hipMemcpyDeviceToHost));
     double md = 0; size_t bad = 0, first = 0;
@@ -64,6 +70,9 @@ int main() {
     int f = 0;
     f |= check<4, 0>(1, 16, 16, 64, 64);
     f |= check<8, 0>(2, 24, 40, 64, 64);
+    f |= check<9, 0>(1, 16, 16, 64, 64);
+    f |= check<9, 0>(2, 24, 40, 64, 64);
+    f |= check<9, 0>(1, 37, 53, 128, 96);
     for (int tap = 0; tap < 9; ++tap) { printf("tap %d: ", tap); f |= check<4>(1, 8, 8, 64, 64, tap); }
     printf("delta tap 4 + random bias: "); f |= check<4>(1, 8, 8, 64, 64, 13);
     printf("random weights, zero bias: "); f |= check<4>(1, 8, 8, 64, 64, -2);
