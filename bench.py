@@ -29,7 +29,7 @@ EPI_BITS = {"E_RELU": 1, "E_LRELU": 2, "E_NORM1": 4, "E_RES": 8, "E_RES_UPS": 16
 
 def rocprof_name(kernel):
     """bench kernel label -> the demangled name rocprofv3 reports, e.g.
-    'conv_wino<E_RELU | E_POOL>' -> 'void conv_wino_k<65, 0, 8, 0>(ConvP)'."""
+    'conv_wino<E_RELU | E_POOL>' -> 'void conv_wino_split_k<65, 0>(ConvP)'."""
     if "<" not in kernel:
         return kernel + "_k"
     base, args = kernel.split("<", 1)
@@ -37,9 +37,9 @@ def rocprof_name(kernel):
     def epi(txt):
         txt = txt.strip()
         return str(sum(EPI_BITS[t.strip()] for t in txt.split("|"))) if txt[:2] == "E_" else txt
-    if base == "conv_wino":      # <EPI, ABL, waves, UPS>: rerevst_hip.hip WINO_NW / UPW_NW
-        return "void conv_wino_k<%s, 0, 8, 0>(ConvP)" % epi(args)
-    if base == "conv_upw":
+    if base == "conv_wino":      # the row-split 8-wave kernel, <EPI, ABL>
+        return "void conv_wino_split_k<%s, 0>(ConvP)" % epi(args)
+    if base == "conv_upw":       # conv_wino_k<EPI, ABL, waves, UPS>: rerevst_hip.hip UPW_NW
         return "void conv_wino_k<%s, 0, 4, 1>(ConvP)" % epi(args)
     if base == "conv_mfma":
         bn, taps, e = args.split(",", 2)

@@ -7,6 +7,7 @@
 #include <math.h>
 #include "../rerevst-code_amd/csrc/conv_mfma.h"
 #include "../rerevst-code_amd/csrc/conv_wino.h"
+#include "../rerevst-code_amd/csrc/conv_wino_split.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -40,6 +41,26 @@ float run_wino(ConvP p, int iters, int xcd = 0) {
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL, NW>), grid, dim3(NW * 64), (WinoGeo<NW, 0>::SMEM), 0, p);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+template <int ABL>
+float run_split(ConvP p, int iters) {
+    p.xcd_slabs = 1;
+    p.tiles_y = (p.H + 15) / 16;
+    int items = p.tiles_x * p.tiles_y * p.B * (p.Cout / 32);
+    dim3 grid(items < 256 ? items : 256, 1);
+    CK(hipFuncSetAttribute((const void*)conv_wino_split_k<E_RELU, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_wino_split_k<E_RELU, ABL>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_split_k<E_RELU, ABL>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, p);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -82,6 +103,11 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     printf("%-28s base %.3f ms %.1f TF | noload %.1f | nobarrier %.1f | noload+nobar %.1f | nostore %.1f | none %.1f TF  (WGs=%d)\n", name, t0,
            fl / t0 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9, fl / t3 / 1e9, fl / t4 / 1e9, fl / t7 / 1e9,
            p.tiles_x * p.tiles_y * B * (Cout / BN));
+    {
+        float a0 = run_split<0>(p, it), a1 = run_split<1>(p, it), a2 = run_split<2>(p, it), a4 = run_split<4>(p, it), a7 = run_split<7>(p, it);
+        printf("%-28s WINO row-split %.3f ms = %.1f TF-eq | noload %.1f | nobarrier %.1f | nostore %.1f | none %.1f\n", name, a0, fl / a0 / 1e9, fl / a1 / 1e9,
+               fl / a2 / 1e9, fl / a4 / 1e9, fl / a7 / 1e9);
+    }
     {   // 8-wave form against the 4-wave form (same transforms, same summation order per accumulator)
         ConvP q = p; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
         int items = q.tiles_x * q.tiles_y * q.B * (q.Cout / 32);
