@@ -85,11 +85,22 @@ __device__ __forceinline__ void bufld16(const void* base, char* lds_wave_base, i
 #endif
 }
 
-// Same with an enable flag folded into the descriptor: num_records = 0 makes every lane out of range, which the
-// hardware turns into "no fetch, zeros written" — a wave-uniform condition without a branch in the MFMA stream.
-__device__ __forceinline__ void bufld16_if(bool en, const void* base, char* lds_wave_base, int voff, int soff) {
+// The same through a descriptor built once and reused by several loads.  num_records = 0 makes every lane out of
+// range, which the hardware turns into "no fetch, zeros written": a wave-uniform off switch without a branch.  (The descriptor type exists in the device pass only.)
 #if defined(__HIP_DEVICE_COMPILE__)
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, en ? 0x7fffffff : 0, 0x00020000);
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#else
+struct rsrc_t {};
+#endif
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int num_records = 0x7fffffff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, num_records, 0x00020000);
+#else
+    return rsrc_t{};
+#endif
+}
+__device__ __forceinline__ void bufld16_rs(rsrc_t rs, char* lds_wave_base, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 #endif
 }

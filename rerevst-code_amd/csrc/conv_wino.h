@@ -192,6 +192,8 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
         else { const int half = P >= G::HALF, rem = P - half * G::HALF; hy = rem / 9; hx = 2 * (rem - hy * 9) + half; swz = (hx >> 1) & 3; }
         asrc[it] = ((hy * (p.Wi + 2) + hx) * p.Cin + 4 * (qq ^ swz)) * 4;
     }
+    const int raw_last_num = ((G::RAW_IT - 1) * NT + wave * 64 < G::PIECES) ? 0x7fffffff : 0;
+    const int u_last_num = ((G::U_IT - 1) * NT + wave * 64 < G::U_PIECES) ? 0x7fffffff : 0;
     bool have = cur.b < p.B, have_nxt = false;
     const float* in_t = in_of(cur);
     const float* w_t = w_of(cur);
@@ -277,9 +279,11 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
         // instructions are spread over the first iterations of the MFMA loop: the four waves share one address
         // unit (~16 clk per 1 KB instruction); issued back to back they stall there.
         const bool own_u = c + 1 < nchunks, own_r = c + 2 < nchunks;
-        const bool en_u = own_u || have_nxt, en_r = own_r || have_nxt;
-        const float* const ubase = own_u ? w_t : w_n;
-        const float* const rbase = own_r ? in_t : in_n;
+        // one descriptor per stream and chunk; in the last slot of a stream the waves past the tile's end are switched off
+        const rsrc_t rs_u = make_rsrc(own_u ? w_t : w_n);
+        const rsrc_t rs_ul = make_rsrc(own_u ? w_t : w_n, u_last_num);
+        const rsrc_t rs_r = make_rsrc(own_r ? in_t : in_n);
+        const rsrc_t rs_rl = make_rsrc(own_r ? in_t : in_n, raw_last_num);
         const int usoff = own_u ? (c + 1) * U_BYTES : 0;
         const int rsoff = (own_r ? c + 2 : c + 2 - nchunks) * 64;
         char* const udst = smem + 2 * RAW_BYTES + (1 - PAR) * U_LDS;
@@ -330,10 +334,8 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
             else lds_release1<G::younger(i)>(u[i & 3][0]);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
-                if constexpr (i < G::U_IT)
-                    bufld16_if(en_u && (i * NT + wave * 64 < G::U_PIECES), ubase, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
-                if constexpr (i < G::RAW_IT)
-                    bufld16_if(en_r && (i * NT + wave * 64 < G::PIECES), rbase, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
+                if constexpr (i < G::U_IT) bufld16_rs(i == G::U_IT - 1 ? rs_ul : rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
+                if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
             }
             const f32x4 vv = vcur[(i % PW) * PW + i / PW];
 #pragma unroll
@@ -375,8 +377,8 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
         const int e_y0 = cur.ty * 16, e_x0 = cur.tx * 16, e_b = cur.b, e_ntile = cur.nt;
         nxt = advance(cur);
         have_nxt = nxt.b < p.B;
-        in_n = in_of(nxt);
-        w_n = w_of(nxt);
+        in_n = have_nxt ? in_of(nxt) : in_t;      // no next item: the last two chunks re-request this item's first tiles
+        w_n = have_nxt ? w_of(nxt) : w_t;         // (valid memory, free LDS buffers, nobody reads them)
         if (par_ntile != e_ntile) {            // (never re-staged when gridDim.x is a multiple of the slab count)
             __syncthreads();                       // slower waves may still read the old slab's parameters
             stage_params(e_ntile);                 // lands before the first K-loop barrier

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         const int hy = rem / 9, hx = 2 * (rem - hy * 9) + hf;
         asrc[it] = ((hy * (p.Wi + 2) + hx) * p.Cin + 4 * (qq ^ ((hx >> 1) & 3))) * 4;
     }
+    const int raw_last_num = ((G::RAW_IT - 1) * NT + wave * 64 < G::PIECES) ? 0x7fffffff : 0;
     bool have = cur.b < p.B, have_nxt = false;
     const float* in_t = in_of(cur);
     const float* w_t = w_of(cur);
@@ -167,9 +168,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         // U(c+1) -> U buffer (c+1)&1, raw(c+2) -> raw buffer c&1; past the end of the item the same slots carry the
         // next item's U(0), raw(0), raw(1).  LDS-DMA instructions are spread over the first MFMA-loop iterations.
         const bool own_u = c + 1 < nchunks, own_r = c + 2 < nchunks;
-        const bool en_u = own_u || have_nxt, en_r = own_r || have_nxt;
-        const float* const ubase = own_u ? w_t : w_n;
-        const float* const rbase = own_r ? in_t : in_n;
+        const rsrc_t rs_u = make_rsrc(own_u ? w_t : w_n);
+        const rsrc_t rs_r = make_rsrc(own_r ? in_t : in_n);
+        const rsrc_t rs_rl = make_rsrc(own_r ? in_t : in_n, raw_last_num);   // last raw slot: waves past the tile's end are switched off
         const int usoff = own_u ? (c + 1) * U_BYTES : 0;
         const int rsoff = (own_r ? c + 2 : c + 2 - nchunks) * 64;
         char* const udst = smem + 2 * RAW_BYTES + (1 - PAR) * U_LDS;
@@ -197,10 +198,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
             lds_release2<S::younger(i)>(u[i & 3][0], u[i & 3][1]);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
-                if constexpr (i < G::U_IT)
-                    bufld16_if(en_u, ubase, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
-                if constexpr (i < G::RAW_IT)
-                    bufld16_if(en_r && (i * NT + wave * 64 < G::PIECES), rbase, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
+                if constexpr (i < G::U_IT) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
+                if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
             }
             const f32x4 vv = vcur[(i & 3) * 2 + (i >> 2)];
 #pragma unroll
@@ -235,8 +234,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         const int e_y0 = cur.ty * 16, e_x0 = cur.tx * 16, e_b = cur.b, e_ntile = cur.nt;
         nxt = advance(cur);
         have_nxt = nxt.b < p.B;
-        in_n = in_of(nxt);
-        w_n = w_of(nxt);
+        in_n = have_nxt ? in_of(nxt) : in_t;      // no next item: the last two chunks re-request this item's first tiles
+        w_n = have_nxt ? w_of(nxt) : w_t;         // (valid memory, free LDS buffers, nobody reads them)
         if (par_ntile != e_ntile) {            // (never re-staged when gridDim.x is a multiple of the slab count)
             __syncthreads();                       // slower waves may still read the old slab's parameters
             stage_params(e_ntile);                 // lands before the first K-loop barrier
