@@ -15,11 +15,12 @@
 // Y = A^T M A couples the four rows, so at the end of an item the partner's row sum T'[r][j] = sum_k M[r][k] A[k][j]
 // crosses through LDS (one 16-byte vector per output pixel and channel block, one barrier per item):
 //   output row i = half:  Y[i][j] = T'c0[j] + sgn * T'c1[j] + (partner's T'c1[j])
-// (max-pool layers: the odd wave ships both of its rows and the even wave finishes all four pixels).
+// (max-pool layers need all four pixels of a tile in one lane: wave `half` finishes channel block `half` and gets
+// the partner's two row sums of that block instead — the same four vectors, the epilogue stays balanced).
 #pragma once
 #include "conv_wino.h"
 
-#define WSPLIT_XCH_BYTES 32768          /* exchange: 8 waves x 4 vectors (pool: 4 waves x 8 vectors) x 64 lanes x 16 B */
+#define WSPLIT_XCH_BYTES 32768          /* exchange: 8 waves x 4 vectors x 64 lanes x 16 B */
 #define WSPLIT_SMEM_BYTES (WinoGeo<8, 0>::SMEM + WSPLIT_XCH_BYTES)   /* 146 KB */
 
 // c = a * s + b on the packed-fp32 pipe
@@ -282,16 +283,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                 T[rl][1][nb] = acc[rl * 4 + 1][nb] - acc[rl * 4 + 2][nb] - acc[rl * 4 + 3][nb];
             }
         // exchange slot (j*2 + nb): 64 lanes x 16 B = 1 KB each
-        if (EPI & E_POOL) {
-            if (half) {
-                char* mine = xch + (wave >> 1) * 8192 + lane * 16;
+        if (EPI & E_POOL) {       // slot rl*2 + j: both rows of the channel block the PARTNER finishes
+            char* mine = xch + wave * 4096 + lane * 16;
 #pragma unroll
-                for (int rl = 0; rl < 2; ++rl)
+            for (int rl = 0; rl < 2; ++rl)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) *(f32x4*)(mine + ((rl * 2 + j) * 2 + nb) * 1024) = T[rl][j][nb];
-            }
+                for (int j = 0; j < 2; ++j) *(f32x4*)(mine + (rl * 2 + j) * 1024) = half ? T[rl][j][0] : T[rl][j][1];
         } else {
             char* mine = xch + wave * 4096 + lane * 16;
 #pragma unroll
@@ -326,15 +323,18 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                 smean = *(const f32x4*)(pl + 1152); sstd = *(const f32x4*)(pl + 1280);
             }
             if (EPI & E_POOL) {
-                if (!half) {      // rows of the odd partner: slot rl 0 = -T'[3], rl 1 = T'[2]
-                    const char* theirs = xch + (wave >> 1) * 8192 + lane * 16;
+                if (nb == half) {
+                    // rows r = 0,1 live in the even wave (A), rows -r3, r2 in the odd one (B):
+                    // Y[0][j] = A0 + A1 + B1,  Y[1][j] = A1 - B1 + B0
+                    const char* theirs = xch + (wave ^ 1) * 4096 + lane * 16;
                     f32x4 pooled;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const f32x4 n3 = *(const f32x4*)(theirs + ((0 * 2 + j) * 2 + nb) * 1024);
-                        const f32x4 t2 = *(const f32x4*)(theirs + ((1 * 2 + j) * 2 + nb) * 1024);
-                        const f32x4 Y0 = T[0][j][nb] + T[1][j][nb] + t2;
-                        const f32x4 Y1 = T[1][j][nb] - t2 + n3;
+                        const f32x4 p0 = *(const f32x4*)(theirs + (0 * 2 + j) * 1024), p1 = *(const f32x4*)(theirs + (1 * 2 + j) * 1024);
+                        const f32x4 A0 = half ? p0 : T[0][j][nb], A1 = half ? p1 : T[1][j][nb];
+                        const f32x4 B0 = half ? T[0][j][nb] : p0, B1 = half ? T[1][j][nb] : p1;
+                        const f32x4 Y0 = A0 + A1 + B1;
+                        const f32x4 Y1 = A1 - B1 + B0;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float a = finish(Y0[e], e, bias, m1, r1, lo1, hi1), b = finish(Y1[e], e, bias, m1, r1, lo1, hi1);
