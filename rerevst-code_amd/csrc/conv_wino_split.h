@@ -195,8 +195,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                 u[n & 3][1] = lds_rd128<UI + k * 2048 + 1024>(n < 4 ? ubA : ubB);
             }
             // column dx = i-2 of the patch was issued in iteration dx, ahead of U(i): complete with it
-            if constexpr (i >= 2 && i <= 5) lds_release3<S::younger(i)>(d[3 * (i - 2) + 0], d[3 * (i - 2) + 1], d[3 * (i - 2) + 2]);
-            lds_release2<S::younger(i)>(u[i & 3][0], u[i & 3][1]);
+            if constexpr (i >= 2 && i <= 5)
+                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(d[3 * (i - 2) + 0]), "+v"(d[3 * (i - 2) + 1]), "+v"(d[3 * (i - 2) + 2]), "+v"(u[i & 3][0]), "+v"(u[i & 3][1]) : "i"(S::younger(i)));
+            else lds_release2<S::younger(i)>(u[i & 3][0], u[i & 3][1]);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
                 if constexpr (i < G::U_IT) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
