@@ -64,7 +64,7 @@ struct WinoGeo {
     static constexpr int OCC = (UPS && NW == 4) ? 2 : 1;     // workgroups per CU
     // MFMA-loop iteration in which column dx of the patch has landed (its last piece was issued three
     // iterations earlier, before U(i)), and the iterations of the row passes
-    static constexpr int col_iter(int dx) { return (dx * PW + PW - 1) / PPI + 3; }
+    static constexpr int col_iter(int dx) { return (dx * PW + PW - 1) / PPI + 3; }      // UPS: dx + 3
     static constexpr int row_iter(int r) { return col_iter(PW - 1) + 1 + r; }
     // LDS reads issued in iteration i: U fragments of position i+2 and up to PPI patch pieces
     static constexpr int pieces_in(int i) { return i < 0 ? 0 : (NPIECE - i * PPI <= 0 ? 0 : (NPIECE - i * PPI < PPI ? NPIECE - i * PPI : PPI)); }
@@ -323,15 +323,20 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
             }, std::make_integer_sequence<int, G::PPI>{});
             // U(i) is complete when at most younger(i) younger reads are outstanding; in-order return also
             // completes every patch piece issued before U(i): those of iterations <= i-3
-            static_for([&](auto xc) {
-                constexpr int dx = decltype(xc)::value;
-                if constexpr (G::col_iter(dx) == i) {
-                    if constexpr (PW == 4) lds_release4<G::younger(i)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
-                    else lds_release3<G::younger(i)>(d[dx * 3 + 0], d[dx * 3 + 1], d[dx * 3 + 2]);
-                }
-            }, std::make_integer_sequence<int, PW>{});
-            if constexpr (NB == 2) lds_release2<G::younger(i)>(u[i & 3][0], u[i & 3][1]);
-            else lds_release1<G::younger(i)>(u[i & 3][0]);
+            constexpr int cdx = i - 3;      // UPS: col_iter(dx) = dx + 3 -> the patch column released in this iteration
+            if constexpr (UPS && NB == 2 && cdx >= 0 && cdx < PW) {   // one s_waitcnt for the column and the U fragments
+                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(d[cdx * 3 + 0]), "+v"(d[cdx * 3 + 1]), "+v"(d[cdx * 3 + 2]), "+v"(u[i & 3][0]), "+v"(u[i & 3][1]) : "i"(G::younger(i)));
+            } else {
+                static_for([&](auto xc) {
+                    constexpr int dx = decltype(xc)::value;
+                    if constexpr (G::col_iter(dx) == i) {
+                        if constexpr (PW == 4) lds_release4<G::younger(i)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
+                        else lds_release3<G::younger(i)>(d[dx * 3 + 0], d[dx * 3 + 1], d[dx * 3 + 2]);
+                    }
+                }, std::make_integer_sequence<int, PW>{});
+                if constexpr (NB == 2) lds_release2<G::younger(i)>(u[i & 3][0], u[i & 3][1]);
+                else lds_release1<G::younger(i)>(u[i & 3][0]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
                 if constexpr (i < G::U_IT) bufld16_rs(i == G::U_IT - 1 ? rs_ul : rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
