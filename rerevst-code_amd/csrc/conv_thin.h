@@ -21,6 +21,7 @@ struct FirstP {
     const float* bias;    // [64]
     int grey;             // 1: content frame (greyscaled), 0: style image (colour)
     int tiles_x, tiles_y;
+    const float* wg;      // grey fold (pack_first_grey_k): W1 [9][64] | W0 [9][64] | bias + sum W0 [64]; null: never fold
 };
 
 __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
@@ -35,8 +36,47 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
     const int y0 = ty * 16, x0 = tx * 16;
     const uint8_t* img = p.img + (size_t)b * p.H * p.W * 3;
 
-    for (int i = tid; i < 27 * 64; i += 256) s_w[i] = p.w[i];
     const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    // A greyscaled frame feeds the three input channels with affine functions of one value g (RGB2Gray + the
+    // re-normalisation, test/style_network_global.py:487-497): 9 multiplies per output instead of 27.  The fold
+    // assumes all nine taps inside the image, so tiles that touch the image border take the general path below.
+    if (p.grey && p.wg && y0 > 0 && x0 > 0 && y0 + 16 < p.H && x0 + 16 < p.W) {
+        float* s_g = s_in;      // [18][18] grey values
+        for (int i = tid; i < 18 * 18; i += 256) {
+            const int hy = i / 18, hx = i - hy * 18;
+            const uint8_t* px = img + ((size_t)(y0 + hy - 1) * p.W + (x0 + hx - 1)) * 3;
+            float d[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = (((float)px[2 - c] / 255.0f - mean[c]) / sd[c]) * sd[c] + mean[c];   // as the reference rounds it
+            s_g[i] = d[2] * 0.299f + d[1] * 0.587f + d[0] * 0.114f;   // :493 (sic)
+        }
+        __syncthreads();
+        const int q = tid & 15, prow = tid >> 4;
+        f32x4 w1[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w1[k] = *(const f32x4*)&p.wg[k * 64 + q * 4];
+        const f32x4 bias = *(const f32x4*)&p.wg[1152 + q * 4];
+        float g[3][18];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 18; ++c) g[r][c] = s_g[(prow + r) * 18 + c];
+        float* orow = p.out + (size_t)b * (size_t)(p.H + 2) * (p.W + 2) * 64 + ((size_t)(y0 + prow + 1) * (p.W + 2) + x0 + 1) * 64 + q * 4;
+#pragma unroll
+        for (int pc = 0; pc < 16; ++pc) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc += w1[ky * 3 + kx] * g[ky][pc + kx];
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e], 0.f);
+            *(f32x4*)&orow[pc * 64] = r;
+        }
+        return;
+    }
+    for (int i = tid; i < 27 * 64; i += 256) s_w[i] = p.w[i];
     for (int i = tid; i < 18 * 18; i += 256) {
         const int hy = i / 18, hx = i - hy * 18;
         const int y = y0 + hy - 1, x = x0 + hx - 1;

@@ -36,6 +36,31 @@ __global__ void pack_first_k(const float* __restrict__ w, float* __restrict__ ds
     }
 }
 
+// conv_first on a greyscaled frame: the three input channels are affine functions of ONE grey value g,
+// x_c = (g - mean_c) / sd_c, so sum_c w[tap][c] x_c = W1[tap] g + W0[tap]:
+// dst[0..575] = W1 [9][64], dst[576..1151] = W0 [9][64], dst[1152..1215] = bias + sum_tap W0 (all nine taps valid).
+__global__ void pack_first_grey_k(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    if (i < 9 * 64) {
+        const int co = i & 63, tap = i >> 6;
+        float w1 = 0.f, w0 = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float wc = w[(co * 3 + c) * 9 + tap];
+            w1 += wc / sd[c];
+            w0 -= wc * (mean[c] / sd[c]);
+        }
+        dst[i] = w1;
+        dst[576 + i] = w0;
+    }
+    if (i < 64) {
+        float b = bias[i];
+        for (int tap = 0; tap < 9; ++tap)
+            for (int c = 0; c < 3; ++c) b -= w[(i * 3 + c) * 9 + tap] * (mean[c] / sd[c]);
+        dst[1152 + i] = b;
+    }
+}
+
 // conv_last weights: OIHW [3][64][3][3] -> [9][64][4]
 __global__ void pack_last_k(const float* __restrict__ w, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

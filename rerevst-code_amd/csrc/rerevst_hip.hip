@@ -87,6 +87,7 @@ struct rrv_ctx {
     bool finalized = false;
     std::map<std::string, ConvW> conv;         // keyed by state_dict prefix (without .weight)
     float *first_w[2] = {nullptr, nullptr}, *first_b[2] = {nullptr, nullptr};   // 0: Encoder, 1: EncoderStyle
+    float* first_wg = nullptr;                                                  // Encoder conv1_1 folded for greyscaled frames
     float *last_w = nullptr, *last_b = nullptr;
     float* fc_w[6] = {nullptr}; float* fc_b[6] = {nullptr};
     float* zero_bias = nullptr;                // 512 zeros
@@ -423,7 +424,8 @@ int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {
 // norm0 != nullptr fuses Decoder.norm[0] into the last conv (per-frame path).
 int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0) {
     const int H = e.H, W = e.W, B = e.B;
-    FirstP fp{d_img, H, W, B, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16};
+    FirstP fp{d_img, H, W, B, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16,
+              which == 0 ? h->first_wg : nullptr};
     RCHK(launch(h, "conv_first", 2.0 * B * H * W * 27 * 64, (3.0 + 256.0) * B * H * W, [&] {
         hipLaunchKernelGGL(conv_first_k, dim3(fp.tiles_x * fp.tiles_y * B), dim3(256), 0, h->stream, fp);
     }));
@@ -675,6 +677,7 @@ int rrv_destroy(rrv_handle h) {
     for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->d_outf) (void)hipFree(h->d_outf);
+    for (float* q : {h->first_w[0], h->first_w[1], h->first_b[0], h->first_b[1], h->first_wg}) if (q) (void)hipFree(q);
     for (auto& st : h->hstage) {
         if (st.pin_in) (void)hipHostFree(st.pin_in);
         if (st.pin_out) (void)hipHostFree(st.pin_out);
@@ -717,6 +720,11 @@ int rrv_finalize_weights(rrv_handle h) {
                 hipLaunchKernelGGL(pack_first_k, dim3(7), dim3(256), 0, h->stream, (const float*)raw, h->first_w[which]);
                 HIPCHK(hipGetLastError());
                 RCHK(upload(h, std::string(k) + ".bias", &h->first_b[which], 64));
+                if (which == 0) {
+                    RCHK(dalloc(h, &h->first_wg, 1216, false));
+                    hipLaunchKernelGGL(pack_first_grey_k, dim3(3), dim3(256), 0, h->stream, (const float*)raw, (const float*)h->first_b[0], h->first_wg);
+                    HIPCHK(hipGetLastError());
+                }
                 HIPCHK(hipStreamSynchronize(h->stream));
                 (void)hipFree(raw);
             } else {
