@@ -243,6 +243,26 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
             stage_params(e_ntile);                 // lands before the first K-loop barrier
             par_ntile = e_ntile;
         }
+        // output geometry of this item; the residual values are requested NOW so that their HBM latency lies under the K loop
+        const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
+        float* out_b = p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
+        const float* res_b = nullptr;
+        if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
+        const int yb = e_y0 + 4 * tg + 2 * tr, xb = e_x0 + 2 * tc;
+        const int y = yb + half;                  // the output row this wave finishes (no-pool layers)
+        f32x4 resv[2][2];                         // [nb][j]
+        if (EPI & (E_RES | E_RES_UPS)) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int x = xb + j;
+                    const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
+                    resv[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (y < p.H && x < p.W)
+                        resv[nb][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + nb * 16 + 4 * q);
+                }
+        }
         chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb);
         if (!(ABL & 2)) __syncthreads();          // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
         chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
@@ -256,25 +276,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;
 
         // ---- output transform: row sums of the wave's two rows, partner's row through LDS, fused epilogue
-        const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
-        float* out_b = p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
-        const float* res_b = nullptr;
-        if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
-        const int yb = e_y0 + 4 * tg + 2 * tr, xb = e_x0 + 2 * tc;
-        const int y = yb + half;                  // the output row this wave finishes (no-pool layers)
-        f32x4 resv[2][2];                         // [nb][j]; requested before the exchange hides their latency
-        if (EPI & (E_RES | E_RES_UPS)) {
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int x = xb + j;
-                    const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
-                    resv[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (y < p.H && x < p.W)
-                        resv[nb][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + nb * 16 + 4 * q);
-                }
-        }
         f32x4 T[2][2][2];                         // [rl][j][nb]: T'[r][j] = sum_k M[r][k] A[k][j]
 #pragma unroll
         for (int rl = 0; rl < 2; ++rl)
