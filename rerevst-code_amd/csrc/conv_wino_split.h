@@ -217,6 +217,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
 
     // ---- persistent loop over (pixel tile, cout slab) work items; only the first item has a prologue (see conv_wino_k)
     int par_ntile = -1;
+    long long tl[4] = {0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
+    auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
+    if (ABL & 16) tl_t = clock64();
     if (have) {
         stage_raw(0);
         stage_u(0);
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                         resv[nb][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + nb * 16 + 4 * q);
                 }
         }
+        tick(0);                                  // item setup (+ previous epilogue's tail)
         chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb);
         if (!(ABL & 2)) __syncthreads();          // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
         chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
             if (!(ABL & 2)) __syncthreads();
         }
         cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;
+        tick(1);                                  // K loop
 
         // ---- output transform: row sums of the wave's two rows, partner's row through LDS, fused epilogue
         f32x4 T[2][2][2];                         // [rl][j][nb]: T'[r][j] = sum_k M[r][k] A[k][j]
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) *(f32x4*)(mine + (j * 2 + nb) * 1024) = T[1][j][nb];
         }
+        tick(2);                                  // row sums + exchange writes
         __syncthreads();
         auto finish = [&](float v, int e, const f32x4& bias, const f32x4& m1, const f32x4& r1, const f32x4& lo1, const f32x4& hi1) {
             float tv = v + bias[e];
@@ -376,5 +382,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                 }
             }
         }
+        tick(3);                                  // barrier + reads + epilogue issue
+    }
+    if ((ABL & 16) && lane == 0) {
+        long long* dbg = (long long*)p.n1;   // microbench passes a debug buffer here
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dbg[(blockIdx.x * 8 + wave) * 4 + k] = tl[k];
     }
 }
