@@ -123,45 +123,63 @@ struct StatP {
 };
 
 __global__ __launch_bounds__(256) void chan_stat_k(const StatP p) {
-    __shared__ double s_red[3][256];
+    // a thread owns 4 consecutive channels (16-byte loads) of every nsub-th pixel of the block's pixel range; the
+    // (b, y, x) decomposition happens once, then advances incrementally
+    __shared__ double s_sum[256][4];
+    __shared__ float s_mn[256][4], s_mx[256][4];
     const int tid = threadIdx.x;
-    const int Cb = p.C < 256 ? p.C : 256;
-    const int nsub = 256 / Cb;
-    const int cl = tid % Cb, sub = tid / Cb;
+    const int CQ = p.C >> 2;                       // channel quads (C is a multiple of 4)
+    const int Qb = CQ < 64 ? CQ : 64;
+    const int nsub = 256 / Qb;
+    const int ql = tid % Qb, sub = tid / Qb;
     const long npix = (long)p.B * p.H * p.W;
     const long p0 = (long)blockIdx.x * p.pix_per_blk;
     long p1 = p0 + p.pix_per_blk;
     if (p1 > npix) p1 = npix;
-    for (int cg = 0; cg < p.C; cg += Cb) {
-        const int c = cg + cl;
-        double s = 0.0;
-        float mn = 3.4e38f, mx = -3.4e38f;
-        const float m = p.pass ? p.mean[c] : 0.f;
-        for (long q = p0 + sub; q < p1; q += nsub) {
-            const int x = (int)(q % p.W);
-            const long r = q / p.W;
-            const int y = (int)(r % p.H);
-            const long b = r / p.H;
-            const float v = p.x[((b * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * (long)p.C + c];
-            if (p.pass) {
-                const float d = v - m;
-                s += (double)(d * d);
-                mn = fminf(mn, v);
-                mx = fmaxf(mx, v);
-            } else {
-                s += (double)v;
+    for (int cg = 0; cg < CQ; cg += Qb) {
+        const int c = 4 * (cg + ql);
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        f32x4 mn = {3.4e38f, 3.4e38f, 3.4e38f, 3.4e38f}, mx = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};
+        if (p.pass) m = *(const f32x4*)(p.mean + c);
+        if (sub < nsub) {
+            long q = p0 + sub;
+            int x = (int)(q % p.W);
+            long r = q / p.W;
+            int y = (int)(r % p.H);
+            long b = r / p.H;
+            for (; q < p1; q += nsub) {
+                const f32x4 v = *(const f32x4*)(p.x + ((b * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * (long)p.C + c);
+                if (p.pass) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[e] - m[e];
+                        s[e] += (double)(d * d);
+                        mn[e] = fminf(mn[e], v[e]);
+                        mx[e] = fmaxf(mx[e], v[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
+                }
+                x += nsub;
+                while (x >= p.W) { x -= p.W; if (++y >= p.H) { y = 0; ++b; } }
             }
         }
-        s_red[0][tid] = s; s_red[1][tid] = mn; s_red[2][tid] = mx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s_sum[tid][e] = s[e]; s_mn[tid][e] = mn[e]; s_mx[tid][e] = mx[e]; }
         __syncthreads();
         if (sub == 0) {
-            for (int k = 1; k < nsub; ++k) {
-                s += s_red[0][k * Cb + cl];
-                mn = fminf(mn, (float)s_red[1][k * Cb + cl]);
-                mx = fmaxf(mx, (float)s_red[2][k * Cb + cl]);
-            }
+            for (int k = 1; k < nsub; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] += s_sum[k * Qb + ql][e];
+                    mn[e] = fminf(mn[e], s_mn[k * Qb + ql][e]);
+                    mx[e] = fmaxf(mx[e], s_mx[k * Qb + ql][e]);
+                }
             double* o = p.part + (size_t)blockIdx.x * 3 * p.C;
-            o[c] = s; o[p.C + c] = mn; o[2 * p.C + c] = mx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[c + e] = s[e]; o[p.C + c + e] = mn[e]; o[2 * p.C + c + e] = mx[e]; }
         }
         __syncthreads();
     }
