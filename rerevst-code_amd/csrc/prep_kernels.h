@@ -188,18 +188,26 @@ __global__ __launch_bounds__(256) void chan_stat_k(const StatP p) {
 // final reduce.  mode 0: mean only -> out[c]
 //               mode 1: content stats -> n[4][C] = mean, rsqrt(ss/N + 1e-8), (min-mean)*rstd, (max-mean)*rstd
 //               mode 2: style stats   -> sty[2][C] = mean, sqrt(ss/(N-1) + 1e-5)
-__global__ void chan_final_k(const double* __restrict__ part, int nblk, int C, double N, int mode,
-                             const float* __restrict__ mean_in, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// launch: C/16 blocks of 256 threads — 16 channels x 16 lanes that each fold every 16th partial, then one LDS step
+__global__ __launch_bounds__(256) void chan_final_k(const double* __restrict__ part, int nblk, int C, double N, int mode,
+                                                    const float* __restrict__ mean_in, float* __restrict__ out) {
+    __shared__ double s_s[16][16];
+    __shared__ float s_mn[16][16], s_mx[16][16];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0;
     float mn = 3.4e38f, mx = -3.4e38f;
-    for (int k = 0; k < nblk; ++k) {
-        const double* o = part + (size_t)k * 3 * C;
-        s += o[c];
-        mn = fminf(mn, (float)o[C + c]);
-        mx = fmaxf(mx, (float)o[2 * C + c]);
-    }
+    if (c < C)
+        for (int k = kl; k < nblk; k += 16) {
+            const double* o = part + (size_t)k * 3 * C;
+            s += o[c];
+            mn = fminf(mn, (float)o[C + c]);
+            mx = fmaxf(mx, (float)o[2 * C + c]);
+        }
+    s_s[kl][cl] = s; s_mn[kl][cl] = mn; s_mx[kl][cl] = mx;
+    __syncthreads();
+    if (kl != 0 || c >= C) return;
+    for (int k = 1; k < 16; ++k) { s += s_s[k][cl]; mn = fminf(mn, s_mn[k][cl]); mx = fmaxf(mx, s_mx[k][cl]); }
     if (mode == 0) {
         out[c] = (float)(s / N);
     } else if (mode == 1) {

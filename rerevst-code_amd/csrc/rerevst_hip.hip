@@ -105,6 +105,7 @@ struct rrv_ctx {
     int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
     float* d_outf = nullptr; size_t d_outf_cap = 0;
+    double* stat_part = nullptr; float* stat_mean = nullptr;      // chan_stats scratch
     // host-buffer entry: two staging sets (pinned host + device, input and output) so that H2D / kernels / D2H /
     // the copies from and to the caller's pageable arrays of consecutive sub-batches overlap
     struct HostStage { uint8_t* pin_in = nullptr; float* pin_out = nullptr; uint8_t* d_in = nullptr; float* d_out = nullptr;
@@ -336,27 +337,27 @@ int chan_stats(rrv_handle h, const Tens& t, int mode, float* out) {
     if (nblk > 1024) nblk = 1024;
     if (nblk < 1) nblk = 1;
     const int ppb = (int)((npix + nblk - 1) / nblk);
-    double* part = nullptr;
-    float* mean = nullptr;
-    HIPCHK(hipMalloc((void**)&part, (size_t)nblk * 3 * t.C * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&mean, (size_t)t.C * sizeof(float)));
+    // scratch shared by all calls: they are ordered on h->stream (1024 partial blocks x 3 x 512 channels at most)
+    if (!h->stat_part) HIPCHK(hipMalloc((void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
+    if (!h->stat_mean) HIPCHK(hipMalloc((void**)&h->stat_mean, 512 * sizeof(float)));
+    if (t.C > 512) return fail(h, RRV_E_ARG, "chan_stats: more than 512 channels");
+    double* part = h->stat_part;
+    float* mean = h->stat_mean;
     StatP sp{t.p, t.B, t.H, t.W, t.C, nullptr, part, 0, ppb};
-    const int fb = (t.C + 63) / 64;
+    const int fb = (t.C + 15) / 16;
     RCHK(launch(h, "chan_stat", 0, 0, [&] { hipLaunchKernelGGL(chan_stat_k, dim3(nblk), dim3(256), 0, h->stream, sp); }));
     RCHK(launch(h, "chan_final", 0, 0, [&] {
-        hipLaunchKernelGGL(chan_final_k, dim3(fb), dim3(64), 0, h->stream, (const double*)part, nblk, t.C, (double)npix, 0,
+        hipLaunchKernelGGL(chan_final_k, dim3(fb), dim3(256), 0, h->stream, (const double*)part, nblk, t.C, (double)npix, 0,
                            (const float*)nullptr, mode == 0 ? out : mean);
     }));
     if (mode != 0) {
         sp.pass = 1; sp.mean = mean;
         RCHK(launch(h, "chan_stat", 0, 0, [&] { hipLaunchKernelGGL(chan_stat_k, dim3(nblk), dim3(256), 0, h->stream, sp); }));
         RCHK(launch(h, "chan_final", 0, 0, [&] {
-            hipLaunchKernelGGL(chan_final_k, dim3(fb), dim3(64), 0, h->stream, (const double*)part, nblk, t.C, (double)npix, mode,
+            hipLaunchKernelGGL(chan_final_k, dim3(fb), dim3(256), 0, h->stream, (const double*)part, nblk, t.C, (double)npix, mode,
                                (const float*)mean, out);
         }));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(part); (void)hipFree(mean);
     return RRV_OK;
 }
 
@@ -677,6 +678,8 @@ int rrv_destroy(rrv_handle h) {
     for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->d_outf) (void)hipFree(h->d_outf);
+    if (h->stat_part) (void)hipFree(h->stat_part);
+    if (h->stat_mean) (void)hipFree(h->stat_mean);
     for (float* q : {h->first_w[0], h->first_w[1], h->first_b[0], h->first_b[1], h->first_wg}) if (q) (void)hipFree(q);
     for (auto& st : h->hstage) {
         if (st.pin_in) (void)hipHostFree(st.pin_in);

@@ -11,3 +11,10 @@ for rep in range(3):
     for f in frames: s.add(f)
     t2 = time.perf_counter(); s.compute(); t3 = time.perf_counter()
     print("prepare_style %.1f ms | %d x add %.1f ms (%.2f each) | compute %.1f ms | total %.1f ms" % (1e3*(t1-t0), len(frames), 1e3*(t2-t1), 1e3*(t2-t1)/len(frames), 1e3*(t3-t2), 1e3*(t3-t0)))
+s.clean()
+for f in frames: s.add(f)
+s.profile_begin(); s.compute(); rows = s.profile_end()
+agg = {}
+for name, ms, fl, by, fx in rows:
+    k = name.split("@")[0]; a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += ms
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]): print("  %-60s x%-3d %.2f ms" % (k, a[0], a[1]))
