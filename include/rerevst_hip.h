@@ -99,6 +99,14 @@ int rrv_transfer_batch(rrv_handle h, const uint8_t* frames_bgr, int B, int H, in
 int rrv_transfer_blend(rrv_handle h, const uint8_t* frame_bgr, int H, int W, const float* style_weight, int n_styles,
                        float* out_bgr);
 
+/* The reference driver's ReshapeTool + crop on the device (test/generate_real_video.py:61-83 process: reflect-pad
+ * 64 px on every side and up to a multiple of 64, cv2.BORDER_REFLECT; :167 crop [64:64+H, 64:64+W]): UNPADDED
+ * [B][H][W][3] uint8 frames in, [B][H][W][3] float32 stylized frames out.  The padded frame never exists: the first
+ * kernel reads the source through the reflection, the last one writes only the crop window.  Bit-identical to
+ * pad -> rrv_transfer_batch -> crop.  _device: HBM buffers, asynchronous; the host form pipelines sub-batches. */
+int rrv_transfer_frames_device(rrv_handle h, const void* d_frames_bgr_u8, int B, int H, int W, void* d_out_bgr_f32);
+int rrv_transfer_frames(rrv_handle h, const uint8_t* frames_bgr, int B, int H, int W, float* out_bgr);
+
 /* Multi-style feature API ("Multi-style Interpolation/stylization.py"): generate_content_features :87-92
  * (encode a frame once; the reference caches the tensor on disk, test.py:87-101 — here it stays in HBM and
  * an integer id is returned), add_patch :66-67 (sample a cached feature for the statistics pass; then

@@ -22,7 +22,19 @@ struct FirstP {
     int grey;             // 1: content frame (greyscaled), 0: style image (colour)
     int tiles_x, tiles_y;
     const float* wg;      // grey fold (pack_first_grey_k): W1 [9][64] | W0 [9][64] | bias + sum W0 [64]; null: never fold
+    // optional on-device ReshapeTool.process (test/generate_real_video.py:61-83): img is the UNPADDED [B][src_H][src_W][3]
+    // frame and padded pixel (y, x) reads source pixel (reflect(y - pad_top), reflect(x - pad_left)), edge-inclusive
+    // (cv2.BORDER_REFLECT = numpy 'symmetric').  src_H == 0: img already has the padded geometry.
+    int src_H, src_W, pad_top, pad_left;
 };
+
+// symmetric (edge-inclusive) reflection of t into [0, n), any distance
+__device__ __forceinline__ int reflect_sym(int t, int n) {
+    const int period = 2 * n;
+    t %= period;
+    if (t < 0) t += period;
+    return t < n ? t : period - 1 - t;
+}
 
 __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
     __shared__ __attribute__((aligned(16))) float s_in[18 * 18 * 4];
@@ -34,7 +46,12 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
     const int ty = bx % p.tiles_y;
     const int b = bx / p.tiles_y;
     const int y0 = ty * 16, x0 = tx * 16;
-    const uint8_t* img = p.img + (size_t)b * p.H * p.W * 3;
+    const int SH = p.src_H ? p.src_H : p.H, SW = p.src_H ? p.src_W : p.W;
+    const uint8_t* img = p.img + (size_t)b * SH * SW * 3;
+    auto src_px = [&](int y, int x) {       // padded-frame pixel -> address in the source frame
+        if (p.src_H) { y = reflect_sym(y - p.pad_top, SH); x = reflect_sym(x - p.pad_left, SW); }
+        return img + ((size_t)y * SW + x) * 3;
+    };
 
     const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
     // A greyscaled frame feeds the three input channels with affine functions of one value g (RGB2Gray + the
@@ -44,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
         float* s_g = s_in;      // [18][18] grey values
         for (int i = tid; i < 18 * 18; i += 256) {
             const int hy = i / 18, hx = i - hy * 18;
-            const uint8_t* px = img + ((size_t)(y0 + hy - 1) * p.W + (x0 + hx - 1)) * 3;
+            const uint8_t* px = src_px(y0 + hy - 1, x0 + hx - 1);
             float d[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) d[c] = (((float)px[2 - c] / 255.0f - mean[c]) / sd[c]) * sd[c] + mean[c];   // as the reference rounds it
@@ -82,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
         const int y = y0 + hy - 1, x = x0 + hx - 1;
         float o[3] = {0.f, 0.f, 0.f};
         if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
-            const uint8_t* px = img + ((size_t)y * p.W + x) * 3;
+            const uint8_t* px = src_px(y, x);
             float n[3];   // normalised, RGB order (framework.py:27,33-34)
 #pragma unroll
             for (int c = 0; c < 3; ++c) n[c] = ((float)px[2 - c] / 255.0f - mean[c]) / sd[c];
@@ -140,6 +157,9 @@ struct LastP {
     float* out_img;       // [B][H][W][3] BGR float32 0..255
     float* out_pre;       // optional [B][H][W][3] RGB pre-clamp (normalised units), may be null
     int tiles_x, tiles_y;
+    // optional on-device crop (generate_real_video.py:167): out_img is [B][out_H][out_W][3] and receives the window
+    // that starts at (crop_top, crop_left) of the padded frame.  out_H == 0: the whole padded frame.
+    int out_H, out_W, crop_top, crop_left;
 };
 
 // Matrix-core form: v_mfma_f32_4x4x1_16B_f32 runs 16 independent 4x4 outer products per instruction
@@ -212,7 +232,13 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
                 if (p.out_pre) p.out_pre[o + jb] = t;
                 float im = t * sj + mj;
                 im = fminf(fmaxf(im, 0.f), 1.f) * 255.f;
-                p.out_img[o + 2 - jb] = im;   // RGB -> BGR
+                if (!p.out_H) {
+                    p.out_img[o + 2 - jb] = im;   // RGB -> BGR
+                } else {
+                    const int cy = y - p.crop_top, cx = x - p.crop_left;
+                    if (cy >= 0 && cy < p.out_H && cx >= 0 && cx < p.out_W)
+                        p.out_img[(((size_t)b * p.out_H + cy) * p.out_W + cx) * 3 + 2 - jb] = im;
+                }
             }
         }
     }

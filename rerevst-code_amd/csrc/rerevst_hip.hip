@@ -423,10 +423,13 @@ int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {
 
 // vgg19.features[0:21] on a device-resident uint8 BGR image.  which: 0 Encoder (grey), 1 EncoderStyle (colour).
 // norm0 != nullptr fuses Decoder.norm[0] into the last conv (per-frame path).
-int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0) {
+// unpadded source frame behind a padded geometry (ReshapeTool on the device): pad on the way in, crop on the way out
+struct PadCrop { int src_H, src_W, top, left; };
+
+int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0, const PadCrop* pc = nullptr) {
     const int H = e.H, W = e.W, B = e.B;
     FirstP fp{d_img, H, W, B, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16,
-              which == 0 ? h->first_wg : nullptr};
+              which == 0 ? h->first_wg : nullptr, pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
     RCHK(launch(h, "conv_first", 2.0 * B * H * W * 27 * 64, (3.0 + 256.0) * B * H * W, [&] {
         hipLaunchKernelGGL(conv_first_k, dim3(fp.tiles_x * fp.tiles_y * B), dim3(256), 0, h->stream, fp);
     }));
@@ -492,7 +495,8 @@ int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens
 }
 
 // feat != nullptr: skip the encoder and start from a cached raw relu4_1 feature (ring layout, [1,H/8,W/8,512])
-int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, float* d_out, const float* feat = nullptr) {
+int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, float* d_out, const float* feat = nullptr,
+                    const PadCrop* pc = nullptr) {
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
     if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
     if (h->active_src == -1) return fail(h, RRV_E_STATE, "state not computed: call compute() (or set_state) before transfer()");
@@ -514,7 +518,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         const float* n0 = st + SL.norm[N_DEC0];
         RCHK(pointwise(h, src, e.c41, n0, n0 + 512, false, nullptr, 0, nullptr, nullptr, n0 + 1024, n0 + 1536));
     } else {
-        RCHK(run_encoder(h, e, d_in, 0, st + SL.norm[N_DEC0]));
+        RCHK(run_encoder(h, e, d_in, 0, st + SL.norm[N_DEC0], pc));
     }
     const Tens* cur = &e.c41;
     Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
@@ -529,7 +533,8 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     RCHK(resblock_frame(h, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2));
     RCHK(resblock_frame(h, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1));
     RCHK(resblock_frame(h, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0));
-    LastP lp{d.o2.p, H, W, B, h->last_w, h->last_b, d_out, d.pre, (W + 15) / 16, (H + 15) / 16};
+    LastP lp{d.o2.p, H, W, B, h->last_w, h->last_b, d_out, d.pre, (W + 15) / 16, (H + 15) / 16,
+             pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
     RCHK(launch(h, "conv_last", 2.0 * B * H * W * 576 * 3, (256.0 + 12.0) * B * H * W, [&] {
         hipLaunchKernelGGL(conv_last_k, dim3(lp.tiles_x * lp.tiles_y * B), dim3(256), 0, h->stream, lp);
     }));
@@ -897,6 +902,22 @@ int rrv_transfer_batch_device(rrv_handle h, const void* d_in, int B, int H, int 
     return transfer_device(h, (const uint8_t*)d_in, B, H, W, (float*)d_out);
 }
 
+static int padded_size(int n) { return (n + 128 + 63) / 64 * 64; }      // ReshapeTool.process, generate_real_video.py:66-76
+
+// [B][H][W][3] UNPADDED uint8 frames in HBM -> [B][H][W][3] float32 stylized frames in HBM: the reference driver's
+// reflect padding (64 px + up to a multiple of 64) and crop (:61-83, :167) happen inside the first and last kernel
+int rrv_transfer_frames_device(rrv_handle h, const void* d_in, int B, int H, int W, void* d_out) {
+    if (!h || !d_in || !d_out || H < 1 || W < 1) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    if (h->active_src == -2) h->active_src = -1;
+    if (h->active_src == -1) {
+        for (int s = 0; s < RRV_MAX_STYLES; ++s)
+            if (h->styles[s].computed) { RCHK(activate_state(h, s)); break; }
+    }
+    const PadCrop pc{H, W, 64, 64};
+    return transfer_device(h, (const uint8_t*)d_in, B, padded_size(H), padded_size(W), (float*)d_out, nullptr, &pc);
+}
+
 int rrv_transfer_device(rrv_handle h, const void* d_in, int H, int W, void* d_out) {
     return rrv_transfer_batch_device(h, d_in, 1, H, W, d_out);
 }
@@ -963,7 +984,7 @@ static void host_copy(void* dst, const void* src, size_t bytes) {
     memcpy(dst, src, slice < bytes ? slice : bytes);
     for (int t = 1; t < nt; ++t) th[t - 1].join();
 }
-static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out) {
+static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out, bool pad_on_device = false) {
     if (!h || !frames || !out || B < 1) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     const size_t fb = (size_t)H * W * 3;
@@ -1001,7 +1022,7 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
         h->next_slot = (k & 1) % h->n_slots;
         hipStream_t sm = h->streams[h->profiling ? 0 : h->next_slot];
         HIPCHK(hipMemcpyAsync(st.d_in, st.pin_in, (size_t)nb * fb, hipMemcpyHostToDevice, sm));
-        rc = rrv_transfer_batch_device(h, st.d_in, nb, H, W, st.d_out);
+        rc = pad_on_device ? rrv_transfer_frames_device(h, st.d_in, nb, H, W, st.d_out) : rrv_transfer_batch_device(h, st.d_in, nb, H, W, st.d_out);
         if (rc != RRV_OK) break;
         HIPCHK(hipMemcpyAsync(st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, sm));
         HIPCHK(hipEventRecord(st.done, sm));
@@ -1018,6 +1039,10 @@ int rrv_transfer(rrv_handle h, const uint8_t* frame, int H, int W, float* out) {
 
 int rrv_transfer_batch(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out) {
     return host_pipeline(h, frames, B, H, W, out);
+}
+
+int rrv_transfer_frames(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out) {
+    return host_pipeline(h, frames, B, H, W, out, true);
 }
 
 int rrv_transfer_blend(rrv_handle h, const uint8_t* frame, int H, int W, const float* wts, int ns, float* out) {

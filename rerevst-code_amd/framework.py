@@ -143,6 +143,26 @@ class Stylization():
         self._chk(self._lib.rrv_transfer_batch(self._h, a.ctypes.data_as(C.c_void_p), B, H, W, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def transfer_frames(self, frames, out=None):
+        """UNPADDED uint8 BGR frames (a list, or one [B][H][W][3] array) -> [B][H][W][3] float32 stylized frames.
+        The reference driver's ReshapeTool.process + crop (test/generate_real_video.py:61-83, :167) run on the
+        device: bit-identical to pad -> transfer -> crop, without the padded copies on the host or over PCIe."""
+        if isinstance(frames, np.ndarray) and frames.ndim == 4 and frames.dtype == np.uint8 and frames.shape[3] == 3:
+            a = np.ascontiguousarray(frames)
+        else:
+            a = np.stack([_u8_image(f, "frame") for f in frames])
+        B, H, W, _ = a.shape
+        if out is None:
+            out = np.empty((B, H, W, 3), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (B, H, W, 3) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape %r" % ((B, H, W, 3),))
+        self._chk(self._lib.rrv_transfer_frames(self._h, a.ctypes.data_as(C.c_void_p), B, H, W, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def transfer_frames_device(self, d_in_ptr, B, H, W, d_out_ptr):
+        """Same on HBM buffers ([B][H][W][3] uint8 -> [B][H][W][3] float32), asynchronous on the library stream."""
+        self._chk(self._lib.rrv_transfer_frames_device(self._h, C.c_void_p(d_in_ptr), B, H, W, C.c_void_p(d_out_ptr)))
+
     def sync(self):
         self._chk(self._lib.rrv_sync(self._h))
 

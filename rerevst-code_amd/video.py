@@ -72,6 +72,15 @@ def stylize_video(model, frames, style, rank=0, world=1, broadcast=None, interva
     tool = ReshapeTool()
     lo, hi = shard_range(n, rank, world)
     out = {}
+    on_device = getattr(model, "transfer_frames", None)     # pad / crop inside the first / last kernel
+    same = all(f.shape == frames[lo].shape for f in frames[lo:hi]) if hi > lo else False
+    if on_device is not None and same and getattr(model, "use_Global", True):
+        for c0 in range(lo, hi, chunk):
+            idx = list(range(c0, min(hi, c0 + chunk)))
+            styled = on_device([frames[i] for i in idx])
+            for j, i in enumerate(idx):
+                out[i] = styled[j]
+        return out
     # the host-buffer batch entry pipelines sub-batches (copy in / kernels / copy out) inside one call
     batch = getattr(model, "transfer_batch", None)     # a model with only the reference's per-frame transfer() works too
     if batch is None:

@@ -90,6 +90,22 @@ def test_host_batch_pipeline_ragged_count(hip, pkg, oracle):
         hip.transfer_batch(frames, out=np.empty((3, 128, 128, 3), np.float32))
 
 
+@pytest.mark.parametrize("hw", [(40, 56), (512, 512), (20, 150), (67, 33)])
+def test_on_device_pad_and_crop_equals_host_reshape_tool(hw, hip, pkg, oracle):
+    """rrv_transfer_frames (reflect padding inside conv_first_k, crop inside conv_last_k) == ReshapeTool.process ->
+    transfer -> crop of the reference driver (test/generate_real_video.py:61-83, :167), bit for bit; 20x150 and 67x33
+    need odd source sizes and pads wider than the frame (repeated reflection)."""
+    H, W = hw
+    g = load_golden("global_a")
+    hip.set_state(g["state"])
+    frames = [pkg.synth_frame(300 + i, H, W, kind="noise") for i in range(3)]
+    PH, PW = oracle.padded_size(H), oracle.padded_size(W)
+    ref = hip.transfer_batch([oracle.reflect_pad(f, PH, PW) for f in frames])[:, 64:64 + H, 64:64 + W, :]
+    got = hip.transfer_frames(frames)
+    assert got.shape == (3, H, W, 3)
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_multistyle_blend_matches_reference(pkg, weights, oracle):
     """Config-5 path: two styles prepared, per-style state, blended transfer (weights .3/.7)."""
     g = load_golden("multistyle_s2")
