@@ -26,3 +26,20 @@ for nb in (8, 32, 64):
     for i in range(reps): s.transfer_batch(arr, out=out)
     dt = time.perf_counter() - t
     print("   same, stacked input array and reused output array: %.1f frames/s" % (reps * nb / dt))
+# driver-level path: unpadded frames in, cropped stylized frames out
+raw = [pkg.synth_frame(i, 512, 512) for i in range(64)]
+tool = V.ReshapeTool()
+t = time.perf_counter()
+for c0 in range(0, 64, 32):
+    o = s.transfer_batch([tool.process(f) for f in raw[c0:c0 + 32]])[:, 64:576, 64:576, :].copy()
+dt = time.perf_counter() - t
+print("driver path, host ReshapeTool + transfer_batch + crop: %.1f frames/s" % (64 / dt))
+s.transfer_frames(raw[:8])
+t = time.perf_counter()
+for c0 in range(0, 64, 32):
+    o = s.transfer_frames(raw[c0:c0 + 32])
+dt = time.perf_counter() - t
+print("driver path, transfer_frames (pad/crop on the device):  %.1f frames/s" % (64 / dt))
+arr = np.stack(raw); out = np.empty(arr.shape, np.float32); s.transfer_frames(arr, out=out)
+t = time.perf_counter(); s.transfer_frames(arr, out=out); dt = time.perf_counter() - t
+print("   same, stacked input array and reused output array:   %.1f frames/s" % (64 / dt))
