@@ -1,28 +1,30 @@
-// conv_wino.h — 3x3 / pad-1 / stride-1 convolution by Winograd F(2x2,3x3) on the fp32 matrix cores.
+// conv_wino.h — 3x3 convolutions in a transform domain on the fp32 matrix cores: shared helpers, geometry and the
+// kernel conv_wino_k.  In the library conv_wino_k runs the UPSAMPLE-FUSED form (UPS = 1, 4 waves, two workgroups per
+// CU: ResidualBlock.conv1 behind the nearest-x2 upsample, test/style_network_global.py:100-103,116-118); the
+// F(2x2,3x3) layers run on conv_wino_split.h, which reuses everything here.  conv_wino_k's own F(2x2,3x3) forms
+// (UPS = 0; 4 waves, or 8 waves split by channel block) are the A/B references of tools/conv_microbench.hip and
+// tools/upw_check.hip.
 //
-// Same layers and the same fused epilogues as conv_mfma_k (vgg19.features convs,
-// test/style_network_global.py:271-281; ResidualBlock.conv2 :104,119-122), but the 9-tap
-// contraction is replaced by 16 element-wise GEMMs in the transform domain:
-//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A          (2x2 outputs from a 4x4 input patch)
-// 16 multiplies per 4 outputs instead of 36: 2.25x fewer MFMA FLOPs on a path that is bound by the
-// fp32 MFMA rate.  Exact in real arithmetic; in fp32 the rounding differs from the direct form at the
-// 1e-7 level (checked against the same goldens / tolerances).
+// The 9-tap contraction becomes element-wise GEMMs over transform positions:
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A
+// UPS = 0: 2x2 outputs from a 4x4 patch, 16 multiplies instead of 36.  UPS = 1: see WinoGeo below, 9 instead of 36.
+// Exact in real arithmetic; in fp32 the rounding differs from the direct form at the 1e-7 level (checked against
+// the reference goldens with the stated tolerances).
 //
-// Mapping (one 256-thread workgroup = 16x16 output pixels x 32 output channels):
-//  * a wave owns 16 Winograd tiles (2 x 8 tiles = 4 x 16 pixels) and ALL 16 transform positions, using
-//    v_mfma_f32_16x16x4_f32: M = 16 output channels, N = 16 tiles, K = 4 input channels per step.
-//  * lane (t = lane&15, q = lane>>4) reads the 4x4 raw patch of tile t for input channels 4q..4q+3 of
-//    the staged 16-channel chunk (16 ds_read_b128), computes B^T d B in registers (32 float4 adds) and
-//    the result IS its MFMA "B" operand for all 16 positions: the transformed input never touches LDS
-//    or HBM.  Transformed weights U (pre-computed once at weight-pack time) are the "A" operand.
-//  * the accumulator of a lane holds, for its tile, 4 consecutive output channels x 2 blocks x 16
-//    positions, so A^T M A, bias, activation, saved-stat normalise, residual, AdaIN and the 2x2 max
-//    pool (the Winograd output tile IS the pooling window) are all in-register; stores are 16-byte.
-//  * per 16-channel chunk: one barrier, 18x18x16 raw halo + 16x32x16 U block staged by buffer_load..lds,
-//    double buffered (112 KB LDS, one workgroup per CU); the raw tile is staged TWO chunks ahead so that
-//    the patch reads + B^T d B of chunk c+1 are sliced under the MFMAs of chunk c.
-//  * workgroups are persistent (grid = #CUs) and walk the (pixel tile, cout slab) work items; the first
-//    tiles of the next item are requested before the epilogue of the current one.
+// Mapping (one workgroup = 16x16 output pixels x 32 output channels):
+//  * v_mfma_f32_16x16x4_f32 with M = 16 output channels (U = G g G^T, pre-packed, "A" operand), N = 16 tiles,
+//    K = 4 input channels per step.  A wave owns 16 tiles (4 x 16 output pixels).
+//  * lane (t = lane&15, q = lane>>4) reads the raw patch of tile t for input channels 4q..4q+3 of the staged
+//    16-channel chunk, computes B^T d B in registers (packed fp32) and the result IS its MFMA "B" operand: the
+//    transformed input never touches LDS or HBM.
+//  * the accumulators of a lane are positions x 4 consecutive output channels of its own tile, so A^T M A, bias,
+//    activation, saved-stat normalise, residual, AdaIN and the 2x2 max pool (the output tile IS the pooling window)
+//    are in-register; stores are 16-byte.
+//  * per 16-channel chunk: one barrier; raw halo + U block staged by buffer_load..lds, double buffered; the raw tile
+//    is staged TWO chunks ahead so that the patch reads + transform of chunk c+1 are sliced under the MFMAs of
+//    chunk c; LDS reads are issued by inline asm two positions ahead and released by counted s_waitcnt.
+//  * workgroups are persistent and walk (pixel tile, cout slab) items as ONE stream: the last two chunks of an item
+//    request the next item's first tiles and the last chunk body leaves its V(0) in registers (no prologue).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
