@@ -1,12 +1,11 @@
 // conv_mfma.h — implicit-GEMM 3x3 / 1x1 convolution on the gfx950 fp32 matrix cores.
 //
-// Replaces every >=32-channel nn.Conv2d call on the reference's per-frame path
-// (vgg19.features convs of Encoder, test/style_network_global.py:271-281; KernelFilter
-// down/up convs :181-187; ResidualBlock conv1/conv2/conv_shortcut :103-105) together with
-// the pointwise ops the reference runs as separate eager kernels after them: bias,
-// ReLU / LeakyReLU(0.2), MaxPool2d(2) (vgg cfg), F.interpolate(nearest, x2) in front of
-// the conv (:113, conv_wino_k<.., UPS = 1> in conv_wino.h), saved-statistics InstanceNorm.forward (:43-57), the residual adds
-// (:122, :217) and the AdaIN affine (:357-364).
+// The direct form of the conv layer with its fused epilogues (bias, ReLU / LeakyReLU(0.2), MaxPool2d(2),
+// saved-statistics InstanceNorm.forward test/style_network_global.py:43-57, residual adds :122 / :217, AdaIN
+// affine :357-364).  On the per-frame path it now runs the 1x1 ResidualBlock shortcuts (:105, evaluated before
+// the upsample) and, in the preparation pass, the raw-output convs; every 3x3 layer of the per-frame path runs in
+// a transform domain (conv_wino_split.h, conv_wino.h).  This header also defines what all conv kernels share:
+// ConvP, the epilogue flags and the LDS-DMA helpers.
 //
 // Data layout (HBM): activations are NHWC fp32 with a one-pixel ZERO ring:
 //   pixel (b,y,x) of a [B,H,W,C] tensor lives at ((b*(H+2) + y+1)*(W+2) + x+1)*C.
@@ -19,7 +18,7 @@
 // every 2x2 pooling window inside one lane.  K = taps x Cin is walked as
 // (16-channel chunk) x (tap): per chunk the (8+2)x(16+2) input halo tile is staged once in
 // LDS and re-used by all 9 taps (no im2col duplication); per (chunk,tap) a BN x 16 weight
-// block is staged.  Both are copied global->LDS with global_load_lds_dwordx4 (no VGPR
+// block is staged.  Both are copied global->LDS with buffer_load_dwordx4 ... lds (no VGPR
 // round trip), double-buffered, one barrier per (chunk,tap) step.
 //
 // LDS image: [pixel or cout row][16 floats], the four 16-byte pieces of a row XOR-swizzled
