@@ -39,8 +39,8 @@ def rocprof_name(kernel):
         return str(sum(EPI_BITS[t.strip()] for t in txt.split("|"))) if txt[:2] == "E_" else txt
     if base == "conv_wino":      # the row-split 8-wave kernel, <EPI, ABL>
         return "void conv_wino_split_k<%s, 0>(ConvP)" % epi(args)
-    if base == "conv_upw":       # conv_wino_k<EPI, ABL, waves, UPS>: rerevst_hip.hip UPW_NW
-        return "void conv_wino_k<%s, 0, 4, 1>(ConvP)" % epi(args)
+    if base in ("conv_upw", "conv_upw_sc"):       # conv_wino_k<EPI, ABL, waves, UPS, SC>: rerevst_hip.hip UPW_NW
+        return "void conv_wino_k<%s, 0, 4, 1, %d>(ConvP)" % (epi(args), 1 if base.endswith("_sc") else 0)
     if base == "conv_mfma":
         bn, taps, e = args.split(",", 2)
         return "void conv_mfma_k<%s, %s, %s, 0, 0, 1>(ConvP)" % (bn.strip(), taps.strip(), epi(e))

@@ -60,6 +60,7 @@ struct ConvP {
     const float* sty;  // [2][Cout]: style mean, style std
     int tiles_x, tiles_y;
     int xcd_slabs;     // conv_wino_k: co-locate the cout slabs of a pixel tile on one XCD (see conv_wino.h)
+    float* sc_out;     // conv_wino_k<.., UPS = 1, SC = 1>: low-resolution output of the fused 1x1 shortcut [B,Hi,Wi,Cout] (ring layout)
 };
 
 template <int BN>

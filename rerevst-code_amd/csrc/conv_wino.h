@@ -44,11 +44,16 @@
 //     y[2i+1] = (g0+g1) x[i] + g2 x[i+1]   = s x[i] + g2 (x[i+1] - x[i]),     s = g0+g1+g2
 //   i.e. 3 multiplies per 2 outputs: 9 positions per 2x2 outputs in 2-D (36 for the direct form, 16 for the
 //   a parity-folded 2x2 conv), 3x3 patches one pixel apart, 10x10 low-resolution halo, all coefficients +-1.
-template <int NW, int UPS>
+// SC = 1 (with UPS): the ResidualBlock's 1x1 shortcut (test/style_network_global.py:105,113-114) rides along as a
+// TENTH position: conv1x1(up(x)) = up(conv1x1(x)) is one more GEMM on V[0][0] = x[i][j], the centre pixel the
+// upsample-fused transform already holds, with the shortcut weights in the U slot; its output is the low-resolution
+// tensor that conv2's epilogue adds (E_RES_UPS).
+template <int NW, int UPS, int SC = 0>
 struct WinoGeo {
     static constexpr int NT = NW * 64;                       // threads
     static constexpr int NB = NW == 8 ? 1 : 2;               // 16-cout blocks per wave
     static constexpr int NP = UPS ? 9 : 16;                  // transform positions
+    static constexpr int NPU = NP + SC;                      // GEMM positions = U blocks per chunk
     static constexpr int PW = UPS ? 3 : 4;                   // patch width; pieces are indexed dx*PW + dy
     static constexpr int NPIECE = PW * PW;
     static constexpr int PPI = UPS ? 3 : 2;                  // patch pieces read per MFMA-loop iteration
@@ -58,7 +63,7 @@ struct WinoGeo {
     static constexpr int PIECES = HALO * HALO * 4;           // 16-byte pieces of one 16-channel raw halo tile
     static constexpr int RAW_IT = (PIECES + NT - 1) / NT;    // LDS-DMA instructions per thread per raw tile
     static constexpr int RAW_BYTES = RAW_IT * NT * 16;       // 24576 / 8192
-    static constexpr int U_BYTES = NP * 32 * 16 * 4;         // 32768 / 18432
+    static constexpr int U_BYTES = NPU * 32 * 16 * 4;        // 32768 / 18432 / 20480
     static constexpr int U_PIECES = U_BYTES / 16;
     static constexpr int U_IT = (U_PIECES + NT - 1) / NT;
     static constexpr int U_LDS = U_IT * NT * 16;             // LDS bytes per U buffer: a disabled LDS-DMA slot still writes zeros
@@ -70,7 +75,7 @@ struct WinoGeo {
     static constexpr int row_iter(int r) { return col_iter(PW - 1) + 1 + r; }
     // LDS reads issued in iteration i: U fragments of position i+2 and up to PPI patch pieces
     static constexpr int pieces_in(int i) { return i < 0 ? 0 : (NPIECE - i * PPI <= 0 ? 0 : (NPIECE - i * PPI < PPI ? NPIECE - i * PPI : PPI)); }
-    static constexpr int issued(int i) { return (i + 2 < NP ? NB : 0) + pieces_in(i); }
+    static constexpr int issued(int i) { return (i + 2 < NPU ? NB : 0) + pieces_in(i); }
     // LDS reads younger than U(i) when iteration i waits for it (LDS returns in order)
     static constexpr int younger(int i) {
         return i == 0 ? NB + issued(0) : i == 1 ? issued(0) + issued(1) : pieces_in(i - 2) + issued(i - 1) + issued(i);
@@ -126,9 +131,11 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-template <int EPI, int ABL = 0, int NW = 4, int UPS = 0>
-__global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(const ConvP p) {
-    using G = WinoGeo<NW, UPS>;
+template <int EPI, int ABL = 0, int NW = 4, int UPS = 0, int SC = 0>
+__global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_wino_k(const ConvP p) {
+    static_assert(!SC || UPS, "the shortcut rides on the upsample-fused form");
+    using G = WinoGeo<NW, UPS, SC>;
+    constexpr int NPU = G::NPU;
     constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, U_LDS = G::U_LDS, NT = G::NT, NB = G::NB, NP = G::NP, PW = G::PW, NPIECE = G::NPIECE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
     auto in_of = [&](const Item& a) {
         return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)((a.ty * G::TIN) * (p.Wi + 2) + a.tx * G::TIN) * p.Cin;
     };
-    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NP * 32 * 16); };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NPU * 32 * 16); };
     int asrc[G::RAW_IT];
 #pragma unroll
     for (int it = 0; it < G::RAW_IT; ++it) {
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
     const unsigned offU = lds0 + 2 * RAW_BYTES + nb0 * 1024 + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);
     const unsigned offU1 = offU + U_LDS;
 
-    f32x4 acc[NP][NB];
+    f32x4 acc[NPU][NB];
     // transformed input B^T d B of the current / next chunk (ping-pong); V[r][k] lives in element k*PW + r: the
     // raw patch is read straight into the "next" array and both transform passes run in place.
     // UPS = 0: B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]];  UPS = 1: B^T = [[0,1,0],[1,-1,0],[0,-1,1]]
@@ -293,8 +300,8 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
         if (ABL & 128) {   // microbench only: the MFMA stream alone (no LDS reads, no transform)
             f32x4 u01[2] = {vcur[0], vcur[1]};
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const f32x4 vv = vcur[i];
+            for (int i = 0; i < NPU; ++i) {
+                const f32x4 vv = vcur[i < NP ? i : 0];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
         if constexpr (NB == 2) u[1][NB - 1] = lds_rd128<2048 + 1024>(ub);
         static_for([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (i + 2 < NP) {
+            if constexpr (i + 2 < NPU) {
                 u[(i + 2) & 3][0] = lds_rd128<(i + 2) * 2048>(ub);
                 if constexpr (NB == 2) u[(i + 2) & 3][NB - 1] = lds_rd128<(i + 2) * 2048 + 1024>(ub);
             }
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
                 if constexpr (i < G::U_IT) bufld16_rs(i == G::U_IT - 1 ? rs_ul : rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
                 if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
             }
-            const f32x4 vv = vcur[(i % PW) * PW + i / PW];
+            const f32x4 vv = vcur[i < NP ? (i % PW) * PW + i / PW : 0];       // position NP (shortcut): V[0][0], the centre pixel
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
                 if constexpr (G::col_iter(k) == i) col_pass(d, k);
                 if constexpr (G::row_iter(k) == i) row_pass(d, k);
             }, std::make_integer_sequence<int, PW>{});
-        }, std::make_integer_sequence<int, NP>{});
+        }, std::make_integer_sequence<int, NPU>{});
     };
 
     // ---- persistent loop over (pixel tile, cout slab) work items.  Only the first item has a prologue: the last
@@ -425,6 +432,14 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
                         if (y < p.H && x < p.W)
                             resv[nb][i][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + (nb0 + nb) * 16 + 4 * q);
                     }
+        }
+        if constexpr (SC) {      // shortcut output: one low-resolution pixel per tile, no bias (conv_shortcut has none)
+            const int ly = yb >> 1, lx = xb >> 1;
+            if (ly < p.Hi && lx < p.Wi) {
+                float* sc_b = p.sc_out + (size_t)e_b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cout + ((size_t)(ly + 1) * (p.Wi + 2) + lx + 1) * p.Cout;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) *(f32x4*)(sc_b + e_ntile * 32 + (nb0 + nb) * 16 + 4 * q) = acc[NP][nb];
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -526,9 +541,11 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS>::OCC)) void conv_wino_k(
 // Weight transform U = G g G^T, packed as [Cout/32][Cin/16][pos][32 couts][16 floats]; the 16-byte pieces are
 // XOR-swizzled by (cout>>2)&3.  ups = 0: G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (16 positions);
 // ups = 1: G = [[1,1,1],[1,0,0],[0,0,1]] (9 positions, the upsample-fused form above).
-__global__ void pack_wino_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int ups) {
+__global__ void pack_wino_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int ups,
+                            const float* __restrict__ wsc = nullptr) {   // wsc: [Cout][Cin] 1x1 shortcut -> position 9 (ups only)
     constexpr int CH = 16;
-    const int np = ups ? 9 : 16, pw = ups ? 3 : 4;
+    const int npt = ups ? 9 : 16, pw = ups ? 3 : 4;      // transform positions
+    const int np = npt + (wsc ? 1 : 0);                  // U blocks per chunk
     const size_t total = (size_t)Cout * Cin * np;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
@@ -541,6 +558,7 @@ __global__ void pack_wino_k(const float* __restrict__ w, float* __restrict__ dst
         const int e = cl & 3, qs = cl >> 2;
         const int qq = qs ^ ((0 - (j >> 2)) & 3);     // XOR mask (0,3,2,1)[(j>>2)&3]: conflict-free ds_read_b128 of a 16-row fragment
         const int co = n_tile * 32 + j, ci = chunk * CH + qq * 4 + e;
+        if (pos >= npt) { dst[i] = wsc[(size_t)co * Cin + ci]; continue; }
         const float* g = w + ((size_t)co * Cin + ci) * 9;
         const int pr = pos / pw, pc = pos % pw;
         auto G3 = [&](int row, float g0, float g1, float g2) {

@@ -46,6 +46,7 @@ struct ConvW {           // one convolution's device weights
     float* pk = nullptr;     // kernel-native packed
     float* pk_wino = nullptr; // Winograd F(2x2,3x3) transformed pack for conv_wino_k
     float* pk_ups = nullptr; // upsample-fused transform pack (9 positions) for conv_wino_k<.., UPS = 1> (convs behind a nearest-x2 upsample)
+    float* pk_ups_sc = nullptr; // the same with the block's 1x1 shortcut as tenth position (conv_wino_k<.., UPS = 1, SC = 1>)
     float* bias = nullptr;   // [Cout] (zeros for bias-free convs)
     int Cout = 0, Cin = 0, taps = 0, BN = 0;
 };
@@ -173,6 +174,7 @@ struct ConvCall {
     const Tens* in; Tens* out; const ConvW* w;
     int H, W;                 // convolution resolution
     bool ups = false; int epi = 0;
+    Tens* sc_out = nullptr;   // ups only: also produce the fused 1x1 shortcut (needs w->pk_ups_sc)
     const float* n1 = nullptr; const Tens* res = nullptr; const float* n2 = nullptr; const float* sty = nullptr;
     int B = 1;
 };
@@ -194,15 +196,15 @@ const ConvKey CONV_TABLE[] = {
 
 constexpr int WINO_NW = 8;     // waves per Winograd workgroup (conv_wino.h: 8 = two waves per SIMD, one 16-cout block each)
 constexpr int UPW_NW = 4;      // upsample-fused form: 4 waves, 54 KB of LDS, two workgroups per CU
-template <int EPI, int NW, int UPS>
+template <int EPI, int NW, int UPS, int SC>
 void wino_launch(const ConvP& p, dim3 grid, hipStream_t s) {
-    using Geo = WinoGeo<NW, UPS>;
+    using Geo = WinoGeo<NW, UPS, SC>;
     static bool attr_set = false;     // >64 KB of dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM);
+        (void)hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino_k<EPI, 0, NW, UPS>), grid, dim3(NW * 64), Geo::SMEM, s, p);
+    hipLaunchKernelGGL((conv_wino_k<EPI, 0, NW, UPS, SC>), grid, dim3(NW * 64), Geo::SMEM, s, p);
 }
 template <int EPI>
 void wsplit_launch(const ConvP& p, dim3 grid, hipStream_t s) {
@@ -214,22 +216,27 @@ void wsplit_launch(const ConvP& p, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((conv_wino_split_k<EPI>), grid, dim3(512), WSPLIT_SMEM_BYTES, s, p);
 }
 #define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI>, "conv_wino<" #EPI ">"}
-#define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1>, "conv_upw<" #EPI ">"}
+#define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 0>, "conv_upw<" #EPI ">"}
+#define UWS(EPI) {32, 10, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 1>, "conv_upw_sc<" #EPI ">"}
 const ConvKey WINO_TABLE[] = {
     WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
     // KernelFilter 32->512 convs with the folded dynamic filter (+ residual, + AdaIN after Filter3)
     WK(E_RES), WK(E_RES | E_NORM2),
     // ResidualBlock.conv1 behind the nearest-x2 upsample (forward pass / preparation pass)
     UW(E_LRELU | E_NORM1), UW(E_LRELU),
+    // the same with the block's 1x1 shortcut fused in as a tenth position (per-frame path)
+    UWS(E_LRELU | E_NORM1),
 };
 
 int conv(rrv_handle h, const ConvCall& c) {
     const ConvW& w = *c.w;
     const ConvKey* k = nullptr;
     bool wino = false;
+    const bool fuse_sc = c.ups && c.sc_out != nullptr;
+    if (fuse_sc && !w.pk_ups_sc) return fail(h, RRV_E_ARG, "conv: no shortcut-fused pack for this layer");
     if (c.ups ? w.pk_ups != nullptr : w.pk_wino != nullptr) {      // every 3x3 layer with a transform-domain pack runs conv_wino_k
         for (const ConvKey& e : WINO_TABLE)
-            if (e.EPI == c.epi && e.UPS == (int)c.ups) { k = &e; wino = true; break; }
+            if (e.EPI == c.epi && e.UPS == (int)c.ups && (e.TAPS == 10) == fuse_sc) { k = &e; wino = true; break; }
     }
     if (!k && !c.ups) {
         for (const ConvKey& e : CONV_TABLE)
@@ -244,7 +251,11 @@ int conv(rrv_handle h, const ConvCall& c) {
     p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W; p.Cin = w.Cin;
     p.out = c.out->p; p.H = c.H; p.W = c.W; p.Cout = w.Cout; p.B = c.B;
     p.in_bstride0 = 1;
-    p.wpk = wino ? (c.ups ? w.pk_ups : w.pk_wino) : w.pk; p.bias = w.bias;
+    p.wpk = wino ? (c.ups ? (fuse_sc ? w.pk_ups_sc : w.pk_ups) : w.pk_wino) : w.pk; p.bias = w.bias;
+    if (fuse_sc) {
+        if (c.sc_out->H != c.in->H || c.sc_out->W != c.in->W || c.sc_out->C != w.Cout) return fail(h, RRV_E_ARG, "conv: shortcut output geometry mismatch");
+        p.sc_out = c.sc_out->p;
+    }
     if (!p.wpk) return fail(h, RRV_E_ARG, "conv: weights not packed for this kernel"); p.n1 = c.n1; p.n2 = c.n2; p.sty = c.sty;
     if (c.res) { p.res = c.res->p; p.Hr = c.res->H; p.Wr = c.res->W; }
     p.tiles_x = (c.W + 15) / 16; p.tiles_y = (c.H + 7) / 8;
@@ -266,8 +277,10 @@ int conv(rrv_handle h, const ConvCall& c) {
     const double px = (double)c.B * c.H * c.W;
     // algorithmic FLOPs = the reference's direct convolution (taps multiply-adds per output);
     // executed: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 outputs (4 per pixel), the upsample-fused form 9 (2.25 per pixel)
-    const double flops = 2.0 * px * w.Cout * w.Cin * w.taps;
-    const double flops_exec = 2.0 * px * w.Cout * w.Cin * (wino ? (c.ups ? 2.25 : 4.0) : (double)w.taps);
+    // (a fused shortcut adds its own 1x1 conv at the input resolution: one more GEMM position, 2.5 per output pixel)
+    const double flops_sc = fuse_sc ? 2.0 * c.B * c.in->H * c.in->W * (double)w.Cout * w.Cin : 0.0;
+    const double flops = 2.0 * px * w.Cout * w.Cin * w.taps + flops_sc;
+    const double flops_exec = 2.0 * px * w.Cout * w.Cin * (wino ? (c.ups ? (fuse_sc ? 2.5 : 2.25) : 4.0) : (double)w.taps);
     const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * w.Cin + (double)c.B * oh * ow * w.Cout +
                                 (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps);
     hipStream_t s = h->stream;
@@ -313,6 +326,16 @@ int pack_ups(rrv_handle h, ConvW& w) {
     const size_t total = (size_t)w.Cout * w.Cin * 9;
     if (!w.pk_ups) RCHK(dalloc(h, &w.pk_ups, total, false));
     hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_ups, w.Cout, w.Cin, 1);
+    HIPCHK(hipGetLastError());
+    return RRV_OK;
+}
+
+// the ResidualBlock's conv1 pack with the block's 1x1 shortcut as tenth position
+int pack_ups_sc(rrv_handle h, ConvW& w, const ConvW& sc) {
+    if (sc.Cout != w.Cout || sc.Cin != w.Cin || sc.taps != 1) return fail(h, RRV_E_WEIGHTS, "shortcut / conv1 shape mismatch");
+    const size_t total = (size_t)w.Cout * w.Cin * 10;
+    if (!w.pk_ups_sc) RCHK(dalloc(h, &w.pk_ups_sc, total, false));
+    hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_ups_sc, w.Cout, w.Cin, 1, (const float*)sc.raw);
     HIPCHK(hipGetLastError());
     return RRV_OK;
 }
@@ -486,8 +509,9 @@ int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens
     const float* st = h->active;
     const std::string p = std::string("Decoder.") + blk;
     ConvCall c;
-    c = ConvCall{&in, &xs, &h->conv[p + ".conv_shortcut"], in.H, in.W}; c.B = in.B; RCHK(conv(h, c));   // up(conv1x1(x)) == conv1x1(up(x))
-    c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.B = in.B; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1]; RCHK(conv(h, c));
+    // conv1 behind the upsample and, in the same kernel, the 1x1 shortcut at the input resolution: up(conv1x1(x)) == conv1x1(up(x))
+    c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.B = in.B; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1];
+    c.sc_out = &xs; RCHK(conv(h, c));
     c = ConvCall{&a, &o, &h->conv[p + ".conv2"], a.H, a.W}; c.B = in.B;
     c.epi = E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2; c.n1 = st + SL.norm[n2]; c.res = &xs; c.n2 = st + SL.norm[nada]; c.sty = st + SL.sty[sty];
     RCHK(conv(h, c));
@@ -672,6 +696,7 @@ int rrv_destroy(rrv_handle h) {
         if (kv.second.raw) (void)hipFree(kv.second.raw);
         if (kv.second.pk) (void)hipFree(kv.second.pk);
         if (kv.second.pk_ups) (void)hipFree(kv.second.pk_ups);
+        if (kv.second.pk_ups_sc) (void)hipFree(kv.second.pk_ups_sc);
         if (kv.second.pk_wino) (void)hipFree(kv.second.pk_wino);
     }
     for (float* p : h->patches) (void)hipFree(p);
@@ -748,6 +773,7 @@ int rrv_finalize_weights(rrv_handle h) {
         RCHK(pack_ups(h, h->conv[p + ".conv1"]));
         RCHK(make_conv(h, p + ".conv2", bc[b][1], bc[b][1], 9, true));
         RCHK(make_conv(h, p + ".conv_shortcut", bc[b][1], bc[b][0], 1, false));
+        RCHK(pack_ups_sc(h, h->conv[p + ".conv1"], h->conv[p + ".conv_shortcut"]));
     }
     {
         float* raw = nullptr;
