@@ -282,7 +282,8 @@ int conv(rrv_handle h, const ConvCall& c) {
     const double flops = 2.0 * px * w.Cout * w.Cin * w.taps + flops_sc;
     const double flops_exec = 2.0 * px * w.Cout * w.Cin * (wino ? (c.ups ? (fuse_sc ? 2.5 : 2.25) : 4.0) : (double)w.taps);
     const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * w.Cin + (double)c.B * oh * ow * w.Cout +
-                                (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps);
+                                (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps +
+                                (fuse_sc ? (double)c.B * c.in->H * c.in->W * w.Cout + (double)w.Cout * w.Cin : 0.0));
     hipStream_t s = h->stream;
     ConvFn fn = k->fn;
     if (h->profiling) {   // "<kernel>@CinxCout@HxW": bench.py groups by the part before '@'
