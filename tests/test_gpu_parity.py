@@ -106,6 +106,17 @@ def test_on_device_pad_and_crop_equals_host_reshape_tool(hw, hip, pkg, oracle):
     np.testing.assert_array_equal(got, ref)
 
 
+def test_repeated_batches_are_bit_identical(hip, pkg, oracle):
+    """The hand-pipelined kernels (counted LDS / LDS-DMA waits, persistent item stream) must be race-free: the same
+    batch 30 times over both streams gives the same bits every time (tools/soak_determinism.py is the long form)."""
+    g = load_golden("global_a")
+    hip.set_state(g["state"])
+    frames = [oracle.reflect_pad(pkg.synth_frame(400 + i, 136, 200, kind="noise"), 264, 328) for i in range(8)]
+    ref = hip.transfer_batch(frames)
+    for _ in range(30):
+        np.testing.assert_array_equal(hip.transfer_batch(frames), ref)
+
+
 def test_multistyle_blend_matches_reference(pkg, weights, oracle):
     """Config-5 path: two styles prepared, per-style state, blended transfer (weights .3/.7)."""
     g = load_golden("multistyle_s2")
