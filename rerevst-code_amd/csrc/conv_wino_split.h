@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
 
     // ---- persistent loop over (pixel tile, cout slab) work items; only the first item has a prologue (see conv_wino_k)
     int par_ntile = -1;
-    long long tl[4] = {0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
+    long long tl[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
     auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
     if (ABL & 16) tl_t = clock64();
     if (have) {
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         tick(0);                                  // item setup (+ previous epilogue's tail)
         chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb);
         if (!(ABL & 2)) __syncthreads();          // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
+        tick(5);                                  // first chunk incl. its barrier (pipeline refill shows up here)
         chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
         if (!(ABL & 2)) __syncthreads();
         for (int c = 2; c < nchunks; c += 2) {
@@ -279,6 +280,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         }
         cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;
         tick(1);                                  // K loop
+        if (ABL & 32) {                           // microbench only: no epilogue at all (keeps the accumulators alive)
+            f32x4 t = acc[0][0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) if (i || nb) t += acc[i][nb];
+            if (t[0] + t[1] + t[2] + t[3] == 123.456f) p.out[tid] = t[0];
+            continue;
+        }
 
         // ---- output transform: row sums of the wave's two rows, partner's row through LDS, fused epilogue
         f32x4 T[2][2][2];                         // [rl][j][nb]: T'[r][j] = sum_k M[r][k] A[k][j]
@@ -305,6 +315,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         }
         tick(2);                                  // row sums + exchange writes
         __syncthreads();
+        tick(4);                                  // exchange barrier
         auto finish = [&](float v, int e, const f32x4& bias, const f32x4& m1, const f32x4& r1, const f32x4& lo1, const f32x4& hi1) {
             float tv = v + bias[e];
             if (EPI & E_RELU) tv = fmaxf(tv, 0.f);
@@ -387,6 +398,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     if ((ABL & 16) && lane == 0) {
         long long* dbg = (long long*)p.n1;   // microbench passes a debug buffer here
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dbg[(blockIdx.x * 8 + wave) * 4 + k] = tl[k];
+        for (int k = 0; k < 6; ++k) dbg[(blockIdx.x * 8 + wave) * 6 + k] = tl[k];
     }
 }

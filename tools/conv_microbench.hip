@@ -104,27 +104,33 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
            fl / t0 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9, fl / t3 / 1e9, fl / t4 / 1e9, fl / t7 / 1e9,
            p.tiles_x * p.tiles_y * B * (Cout / BN));
     {
-        float a0 = run_split<0>(p, it), a1 = run_split<1>(p, it), a2 = run_split<2>(p, it), a4 = run_split<4>(p, it), a7 = run_split<7>(p, it);
-        printf("%-28s WINO row-split %.3f ms = %.1f TF-eq | noload %.1f | nobarrier %.1f | nostore %.1f | none %.1f\n", name, a0, fl / a0 / 1e9, fl / a1 / 1e9,
-               fl / a2 / 1e9, fl / a4 / 1e9, fl / a7 / 1e9);
+        float a0 = run_split<0>(p, it), a1 = run_split<1>(p, it), a2 = run_split<2>(p, it), a4 = run_split<4>(p, it), a7 = run_split<7>(p, it), a32 = run_split<32>(p, it);
+        printf("%-28s WINO row-split %.3f ms = %.1f TF-eq | noload %.1f | nobarrier %.1f | nostore %.1f | none %.1f | NO EPILOGUE %.1f\n", name, a0, fl / a0 / 1e9, fl / a1 / 1e9,
+               fl / a2 / 1e9, fl / a4 / 1e9, fl / a7 / 1e9, fl / a32 / 1e9);
     }
     {   // row-split kernel: per-phase cycles (wave averages)
-        long long* dbg; CK(hipMalloc(&dbg, (size_t)256 * 8 * 4 * 8));
+        long long* dbg; CK(hipMalloc(&dbg, (size_t)256 * 8 * 6 * 8));
         ConvP q = p; q.n1 = (const float*)dbg; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
         int items = q.tiles_x * q.tiles_y * q.B * (q.Cout / 32);
         dim3 grid(items < 256 ? items : 256, 1);
         CK(hipFuncSetAttribute((const void*)conv_wino_split_k<E_RELU, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES));
-        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((conv_wino_split_k<E_RELU, 16>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, q);
-        CK(hipDeviceSynchronize());
-        std::vector<long long> h((size_t)grid.x * 8 * 4);
-        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double s4[4] = {0}, tot = 0;
-        for (size_t i = 0; i < h.size(); ++i) { s4[i % 4] += h[i]; tot += h[i]; }
-        const char* nm[4] = {"item setup", "K loop", "row sums+xch write", "barrier+epilogue"};
-        const double ipw = (double)items / grid.x;
-        printf("     row-split timeline:");
-        for (int k = 0; k < 4; ++k) printf(" %s %.1f%% (%.0f clk/item) |", nm[k], 100.0 * s4[k] / tot, s4[k] / (grid.x * 8) / ipw);
-        printf(" %.1f items/WG\n", ipw);
+        CK(hipFuncSetAttribute((const void*)conv_wino_split_k<E_RELU, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES));
+        for (int variant = 0; variant < 2; ++variant) {
+            for (int rep = 0; rep < 2; ++rep) {
+                if (variant) hipLaunchKernelGGL((conv_wino_split_k<E_RELU, 20>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, q);
+                else hipLaunchKernelGGL((conv_wino_split_k<E_RELU, 16>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, q);
+            }
+            CK(hipDeviceSynchronize());
+            std::vector<long long> h((size_t)grid.x * 8 * 6);
+            CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            double s6[6] = {0}, tot = 0;
+            for (size_t i = 0; i < h.size(); ++i) { s6[i % 6] += h[i]; tot += h[i]; }
+            const char* nm[6] = {"item setup", "chunks 1..n-1", "row sums+xch write", "reads+epilogue", "xch barrier", "chunk 0"};
+            const double ipw = (double)items / grid.x;
+            printf("     row-split timeline%s (clk/item):", variant ? " NO STORES" : "");
+            for (int k : {0, 5, 1, 2, 4, 3}) printf(" %s %.0f |", nm[k], s6[k] / (grid.x * 8) / ipw);
+            printf(" %d chunks/item, %.1f items/WG\n", q.Cin / 16, ipw);
+        }
         CK(hipFree(dbg));
     }
     {   // 8-wave form against the 4-wave form (same transforms, same summation order per accumulator)
