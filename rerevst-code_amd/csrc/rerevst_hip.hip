@@ -69,6 +69,15 @@ struct DecPlan {   // per-frame decoder activations for one (B, H, W) of the FRA
     float* pre = nullptr;   // [H][W][3] pre-clamp tap
 };
 
+// workspace of the preparation pass (compute_style) for one geometry; kept between calls in frame mode, where the
+// pass runs once per frame
+struct PrepPlan {
+    int B = 0, hh = 0, ww = 0, sH = 0, sW = 0;
+    Tens cn, nxt, sn, t32, ts32, d32, u, xs[3], a[3], o[3];
+    float *cmean = nullptr, *smean = nullptr;
+    float* pre = nullptr;     // frame mode: [8hh][8ww][3] pre-clamp tap of the single-pass finish
+};
+
 struct StyleState {
     bool prepared = false, computed = false;
     float* blob = nullptr;           // RRV_STATE_FLOATS on device
@@ -107,6 +116,8 @@ struct rrv_ctx {
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
     float* d_outf = nullptr; size_t d_outf_cap = 0;
     double* stat_part = nullptr; float* stat_mean = nullptr;      // chan_stats scratch
+    PrepPlan prep;
+    const float* last_pre = nullptr; int last_pre_H = 0, last_pre_W = 0;   // where rrv_get_preclamp finds the last tap
     // host-buffer entry: two staging sets (pinned host + device, input and output) so that H2D / kernels / D2H /
     // the copies from and to the caller's pageable arrays of consecutive sub-batches overlap
     struct HostStage { uint8_t* pin_in = nullptr; float* pin_out = nullptr; uint8_t* d_in = nullptr; float* d_out = nullptr;
@@ -501,7 +512,7 @@ int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {
     RCHK(talloc(h, &d.xs2, B, H2, W2, 64));
     RCHK(talloc(h, &d.a2, B, H, W, 64));
     RCHK(talloc(h, &d.o2, B, H, W, 64));
-    if (d.pre) (void)hipFree(d.pre);
+    if (d.pre) { if (h->last_pre == d.pre) h->last_pre = nullptr; (void)hipFree(d.pre); }
     RCHK(dalloc(h, &d.pre, (size_t)B * H * W * 3, true));
     return RRV_OK;
 }
@@ -517,6 +528,16 @@ int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens
     c.epi = E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2; c.n1 = st + SL.norm[n2]; c.res = &xs; c.n2 = st + SL.norm[nada]; c.sty = st + SL.sty[sty];
     RCHK(conv(h, c));
     return RRV_OK;
+}
+
+// Decoder.slice1 + transform_back_image (conv_last_k) on a normalised slice2 output
+int run_last(rrv_handle h, const Tens& o2, int B, int H, int W, float* d_out, float* pre, const PadCrop* pc) {
+    LastP lp{o2.p, H, W, B, h->last_w, h->last_b, d_out, pre, (W + 15) / 16, (H + 15) / 16,
+             pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
+    h->last_pre = pre; h->last_pre_H = H; h->last_pre_W = W;
+    return launch(h, "conv_last", 2.0 * B * H * W * 576 * 3, (256.0 + 12.0) * B * H * W, [&] {
+        hipLaunchKernelGGL(conv_last_k, dim3(lp.tiles_x * lp.tiles_y * B), dim3(256), 0, h->stream, lp);
+    });
 }
 
 // feat != nullptr: skip the encoder and start from a cached raw relu4_1 feature (ring layout, [1,H/8,W/8,512])
@@ -558,38 +579,62 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     RCHK(resblock_frame(h, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2));
     RCHK(resblock_frame(h, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1));
     RCHK(resblock_frame(h, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0));
-    LastP lp{d.o2.p, H, W, B, h->last_w, h->last_b, d_out, d.pre, (W + 15) / 16, (H + 15) / 16,
-             pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
-    RCHK(launch(h, "conv_last", 2.0 * B * H * W * 576 * 3, (256.0 + 12.0) * B * H * W, [&] {
-        hipLaunchKernelGGL(conv_last_k, dim3(lp.tiles_x * lp.tiles_y * B), dim3(256), 0, h->stream, lp);
-    }));
+    RCHK(run_last(h, d.o2, B, H, W, d_out, d.pre, pc));
     return RRV_OK;
 }
 
 // ---- preparation: Decoder.compute for one style ---------------------------------------------
 // frame_mode: the per-frame-statistics network of test/style_network_frame.py (use_Global=False) is this
 // same pass with B = 1 and no normalisation between the filters and the first AdaIN affine.
+void prep_free(rrv_handle h) {
+    PrepPlan& P = h->prep;
+    for (Tens* t : {&P.cn, &P.nxt, &P.sn, &P.t32, &P.ts32, &P.d32, &P.u}) tfree(t);
+    for (int k = 0; k < 3; ++k) { tfree(&P.xs[k]); tfree(&P.a[k]); tfree(&P.o[k]); }
+    if (P.cmean) (void)hipFree(P.cmean);
+    if (P.smean) (void)hipFree(P.smean);
+    if (P.pre) { if (h->last_pre == P.pre) h->last_pre = nullptr; (void)hipFree(P.pre); }
+    P = PrepPlan{};
+}
+
+int prep_plan(rrv_handle h, int B, int hh, int ww, int sH, int sW) {
+    PrepPlan& P = h->prep;
+    if (P.B == B && P.hh == hh && P.ww == ww && P.sH == sH && P.sW == sW && P.cn.p) return RRV_OK;
+    RCHK(sync_all(h));
+    prep_free(h);
+    P.B = B; P.hh = hh; P.ww = ww; P.sH = sH; P.sW = sW;
+    RCHK(dalloc(h, &P.cmean, 32)); RCHK(dalloc(h, &P.smean, 32));
+    RCHK(talloc(h, &P.cn, B, hh, ww, 512));
+    RCHK(talloc(h, &P.nxt, B, hh, ww, 512));
+    RCHK(talloc(h, &P.sn, 1, sH, sW, 512));
+    RCHK(talloc(h, &P.t32, B, hh, ww, 32));
+    RCHK(talloc(h, &P.ts32, 1, sH, sW, 32));
+    RCHK(talloc(h, &P.d32, 1, hh, ww, 32));
+    RCHK(talloc(h, &P.u, 1, hh, ww, 512));
+    const int cout[3] = {256, 128, 64};
+    for (int k = 0, H = hh, W = ww; k < 3; ++k, H *= 2, W *= 2) {
+        RCHK(talloc(h, &P.xs[k], B, H, W, cout[k]));
+        RCHK(talloc(h, &P.a[k], B, 2 * H, 2 * W, cout[k]));
+        RCHK(talloc(h, &P.o[k], B, 2 * H, 2 * W, cout[k]));
+    }
+    return RRV_OK;
+}
+
+// keep_ws: leave the workspace allocated (frame mode); otherwise it is released at the end (several GB for a video's
+// sampled frames).  After the call P.o[2] holds the slice2 output before Decoder.norm[4] / AdaIN (stats in the blob).
 int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = false) {
     StyleState& S = h->styles[sid];
     float* st = S.blob;
     const int B = content.B, hh = content.H, ww = content.W;
-    Tens cn, nxt, sn, t32, ts32, d32, u, xs, a, o;
-    float *cmean = nullptr, *smean = nullptr;
-    RCHK(dalloc(h, &cmean, 32)); RCHK(dalloc(h, &smean, 32));
-    int rc = RRV_OK;
+    RCHK(prep_plan(h, B, hh, ww, S.map.H, S.map.W));
+    PrepPlan& P = h->prep;
+    Tens &cn = P.cn, &nxt = P.nxt, &sn = P.sn, &t32 = P.t32, &ts32 = P.ts32, &d32 = P.d32, &u = P.u;
+    float *cmean = P.cmean, *smean = P.smean;
     auto body = [&]() -> int {
         // norm[0].compute on the batch (style_network_global.py:396)
         RCHK(chan_stats(h, content, 1, st + SL.norm[N_DEC0]));
-        RCHK(talloc(h, &cn, B, hh, ww, 512));
-        RCHK(talloc(h, &nxt, B, hh, ww, 512));
         RCHK(pointwise(h, content, cn, st + SL.norm[N_DEC0], st + SL.norm[N_DEC0] + 512, false, nullptr, 0, nullptr, nullptr));
         // normalized_style = (style_map - mean)/std (:397)
-        RCHK(talloc(h, &sn, 1, S.map.H, S.map.W, 512));
         RCHK(pointwise(h, S.map, sn, st + SL.sty[3], st + SL.sty[3] + 512, true, nullptr, 0, nullptr, nullptr));
-        RCHK(talloc(h, &t32, B, hh, ww, 32));
-        RCHK(talloc(h, &ts32, 1, S.map.H, S.map.W, 32));
-        RCHK(talloc(h, &d32, 1, hh, ww, 32));
-        RCHK(talloc(h, &u, 1, hh, ww, 512));
         Tens* cur = &cn; Tens* other = &nxt;
         for (int f = 0; f < 3; ++f) {
             char pre[64];
@@ -623,18 +668,15 @@ int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = 
         }
         struct Blk { const char* name; int cout, n1, n2, nada, sty; };
         const Blk blks[3] = {{"slice4", 256, N_S4N1, N_S4N2, N_DEC2, 2}, {"slice3", 128, N_S3N1, N_S3N2, N_DEC3, 1}, {"slice2", 64, N_S2N1, N_S2N2, N_DEC4, 0}};
-        Tens in = *cur;   // shallow view
-        Tens prev_o;      // owns previous block output
+        const Tens* in = cur;
         for (int k = 0; k < 3; ++k) {
             const Blk& b = blks[k];
             const std::string p = std::string("Decoder.") + b.name;
-            const int H2 = in.H * 2, W2 = in.W * 2;
-            RCHK(talloc(h, &xs, B, in.H, in.W, b.cout));
-            RCHK(talloc(h, &a, B, H2, W2, b.cout));
-            RCHK(talloc(h, &o, B, H2, W2, b.cout));
+            Tens &xs = P.xs[k], &a = P.a[k], &o = P.o[k];
+            const int H2 = in->H * 2, W2 = in->W * 2;
             ConvCall c;
-            c = ConvCall{&in, &xs, &h->conv[p + ".conv_shortcut"], in.H, in.W}; c.B = B; RCHK(conv(h, c));
-            c = ConvCall{&in, &a, &h->conv[p + ".conv1"], H2, W2}; c.B = B; c.ups = true; c.epi = E_LRELU; RCHK(conv(h, c));
+            c = ConvCall{in, &xs, &h->conv[p + ".conv_shortcut"], in->H, in->W}; c.B = B; RCHK(conv(h, c));
+            c = ConvCall{in, &a, &h->conv[p + ".conv1"], H2, W2}; c.B = B; c.ups = true; c.epi = E_LRELU; RCHK(conv(h, c));
             RCHK(chan_stats(h, a, 1, st + SL.norm[b.n1]));
             RCHK(pointwise(h, a, a, st + SL.norm[b.n1], st + SL.norm[b.n1] + b.cout, false, nullptr, 0, nullptr, nullptr));
             c = ConvCall{&a, &o, &h->conv[p + ".conv2"], H2, W2}; c.B = B; c.epi = E_LRELU; RCHK(conv(h, c));
@@ -644,19 +686,15 @@ int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = 
             RCHK(chan_stats(h, o, 1, st + SL.norm[b.nada]));
             if (k < 2)
                 RCHK(pointwise(h, o, o, st + SL.norm[b.nada], st + SL.norm[b.nada] + b.cout, false, nullptr, 0, st + SL.sty[b.sty], st + SL.sty[b.sty] + b.cout));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            tfree(&prev_o);
-            prev_o = o; o.p = nullptr;
-            in = prev_o;
-            tfree(&xs); tfree(&a);
+            in = &o;
         }
-        tfree(&prev_o);
         return RRV_OK;
     };
-    rc = body();
-    (void)hipStreamSynchronize(h->stream);
-    tfree(&cn); tfree(&nxt); tfree(&sn); tfree(&t32); tfree(&ts32); tfree(&d32); tfree(&u); tfree(&xs); tfree(&a); tfree(&o);
-    (void)hipFree(cmean); (void)hipFree(smean);
+    const int rc = body();
+    if (!frame_mode || rc != RRV_OK) {
+        (void)hipStreamSynchronize(h->stream);
+        prep_free(h);
+    }
     if (rc == RRV_OK) S.computed = true;
     return rc;
 }
@@ -709,6 +747,7 @@ int rrv_destroy(rrv_handle h) {
     for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->d_outf) (void)hipFree(h->d_outf);
+    prep_free(h);
     if (h->stat_part) (void)hipFree(h->stat_part);
     if (h->stat_mean) (void)hipFree(h->stat_mean);
     for (float* q : {h->first_w[0], h->first_w[1], h->first_b[0], h->first_b[1], h->first_wg}) if (q) (void)hipFree(q);
@@ -1174,18 +1213,21 @@ int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame, int H, int W, fl
     RCHK(enc_plan(h, h->enc_add, 1, H, W));
     RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr));
     Tens content = h->enc_add.c41;          // view: [1, H/8, W/8, 512] raw relu4_1 feature
+    // One pass: the preparation pass on this frame IS the frame-mode forward (per-frame statistics,
+    // test/style_network_frame.py:39-43) up to the last normalisation; finish with Decoder.norm[4] + AdaIN on its
+    // slice2 output and slice1.  (The saved-state forward would only repeat the same arithmetic.)
     RCHK(compute_style(h, 0, content, true));
-    h->active_src = -1;
-    RCHK(activate_state(h, 0));
+    PrepPlan& P = h->prep;
+    const float* st = S.blob;
+    RCHK(pointwise(h, P.o[2], P.o[2], st + SL.norm[N_DEC4], st + SL.norm[N_DEC4] + 64, false, nullptr, 0, st + SL.sty[0], st + SL.sty[0] + 64));
     if (h->d_outf_cap < n) {
         if (h->d_outf) (void)hipFree(h->d_outf);
         h->d_outf = nullptr; h->d_outf_cap = 0;
         HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
         h->d_outf_cap = n;
     }
-    h->next_slot = 0;
-    RCHK(transfer_device(h, h->d_u8, 1, H, W, h->d_outf));
-    h->next_slot = 0;
+    if (!P.pre) RCHK(dalloc(h, &P.pre, n, true));
+    RCHK(run_last(h, P.o[2], 1, H, W, h->d_outf, P.pre, nullptr));
     HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
     HIPCHK(hipStreamSynchronize(h->streams[0]));
     return RRV_OK;
@@ -1193,11 +1235,10 @@ int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame, int H, int W, fl
 
 int rrv_get_preclamp(rrv_handle h, float* out, int H, int W) {
     if (!h || !out) return RRV_E_ARG;
-    const DecPlan& d = h->dec[h->last_slot];
-    if (!d.pre || d.H != H || d.W != W || d.B < 1) return fail(h, RRV_E_STATE, "get_preclamp: no transfer of that size yet");
+    if (!h->last_pre || h->last_pre_H != H || h->last_pre_W != W) return fail(h, RRV_E_STATE, "get_preclamp: no transfer of that size yet");
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
-    HIPCHK(hipMemcpy(out, d.pre, (size_t)H * W * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, h->last_pre, (size_t)H * W * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return RRV_OK;
 }
 
