@@ -368,7 +368,7 @@ int make_conv(rrv_handle h, const std::string& prefix, int cout, int cin, int ta
 // mode 0: out[C] = mean;  mode 1: out = norm params [4][C];  mode 2: out = style (mean,std) [2][C]
 int chan_stats(rrv_handle h, const Tens& t, int mode, float* out) {
     const long npix = (long)t.B * t.H * t.W;
-    int nblk = (int)((npix + 1023) / 1024);
+    int nblk = (int)((npix + 255) / 256);        // small tensors (frame mode, B = 1) still get a few dozen workgroups
     if (nblk > 1024) nblk = 1024;
     if (nblk < 1) nblk = 1;
     const int ppb = (int)((npix + nblk - 1) / nblk);
