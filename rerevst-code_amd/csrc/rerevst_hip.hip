@@ -117,6 +117,9 @@ struct rrv_ctx {
     float* d_outf = nullptr; size_t d_outf_cap = 0;
     double* stat_part = nullptr; float* stat_mean = nullptr;      // chan_stats scratch
     PrepPlan prep;
+    // frames handed to rrv_add wait here (uint8, HBM) and are encoded together, 8 per encoder launch, when their
+    // features are first needed (rrv_compute): the encoder at B = 1 runs at a fraction of its batched rate
+    uint8_t* pend_u8 = nullptr; size_t pend_cap = 0; int pend_n = 0;
     const float* last_pre = nullptr; int last_pre_H = 0, last_pre_W = 0;   // where rrv_get_preclamp finds the last tap
     // host-buffer entry: two staging sets (pinned host + device, input and output) so that H2D / kernels / D2H /
     // the copies from and to the caller's pageable arrays of consecutive sub-batches overlap
@@ -461,8 +464,9 @@ int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {
 // unpadded source frame behind a padded geometry (ReshapeTool on the device): pad on the way in, crop on the way out
 struct PadCrop { int src_H, src_W, top, left; };
 
-int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0, const PadCrop* pc = nullptr) {
-    const int H = e.H, W = e.W, B = e.B;
+// nb > 0: encode only the first nb images of a plan made for more
+int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0, const PadCrop* pc = nullptr, int nb = 0) {
+    const int H = e.H, W = e.W, B = (nb > 0 && nb < e.B) ? nb : e.B;
     FirstP fp{d_img, H, W, B, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16,
               which == 0 ? h->first_wg : nullptr, pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
     RCHK(launch(h, "conv_first", 2.0 * B * H * W * 27 * 64, (3.0 + 256.0) * B * H * W, [&] {
@@ -748,6 +752,7 @@ int rrv_destroy(rrv_handle h) {
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->d_outf) (void)hipFree(h->d_outf);
     prep_free(h);
+    if (h->pend_u8) (void)hipFree(h->pend_u8);
     if (h->stat_part) (void)hipFree(h->stat_part);
     if (h->stat_mean) (void)hipFree(h->stat_mean);
     for (float* q : {h->first_w[0], h->first_w[1], h->first_b[0], h->first_b[1], h->first_wg}) if (q) (void)hipFree(q);
@@ -883,9 +888,34 @@ int rrv_clean(rrv_handle h) {
     (void)sync_all(h);
     for (float* p : h->patches) (void)hipFree(p);
     h->patches.clear();
+    h->pend_n = 0;
     h->patch_h = h->patch_w = h->add_H = h->add_W = 0;
     for (StyleState& s : h->styles) s.computed = false;
     h->active_src = -1;
+    return RRV_OK;
+}
+
+// encode the frames collected by rrv_add (all H x W = add_H x add_W) and append their relu4_1 features to h->patches
+static int flush_pending(rrv_handle h) {
+    if (!h->pend_n) return RRV_OK;
+    const int H = h->add_H, W = h->add_W;
+    const size_t fb = (size_t)H * W * 3;
+    const int PB = h->pend_n < 8 ? h->pend_n : 8;        // one plan; the last group may use fewer of its images
+    RCHK(enc_plan(h, h->enc_add, PB, H, W));
+    for (int k0 = 0; k0 < h->pend_n; k0 += PB) {
+        const int nb = h->pend_n - k0 < PB ? h->pend_n - k0 : PB;
+        RCHK(run_encoder(h, h->enc_add, h->pend_u8 + (size_t)k0 * fb, 0, nullptr, nullptr, nb));
+        const Tens& f = h->enc_add.c41;
+        for (int b = 0; b < nb; ++b) {
+            float* keep = nullptr;
+            RCHK(dalloc(h, &keep, f.img_floats(), false));
+            HIPCHK(hipMemcpyAsync(keep, f.p + (size_t)b * f.img_floats(), f.img_floats() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            h->patches.push_back(keep);
+        }
+        h->patch_h = f.H; h->patch_w = f.W;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->pend_n = 0;
     return RRV_OK;
 }
 
@@ -893,20 +923,20 @@ int rrv_add(rrv_handle h, const uint8_t* frame, int H, int W) {
     if (!h || !frame || H < 8 || W < 8) return RRV_E_ARG;
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
     HIPCHK(hipSetDevice(h->dev));
-    RCHK(sync_all(h));
-    if (!h->patches.empty() && (H != h->add_H || W != h->add_W))
+    if ((!h->patches.empty() || h->pend_n) && (H != h->add_H || W != h->add_W))
         return fail(h, RRV_E_ARG, "add: all sampled frames must have the same size");
-    RCHK(ensure_u8(h, (size_t)H * W * 3));
-    HIPCHK(hipMemcpyAsync(h->d_u8, frame, (size_t)H * W * 3, hipMemcpyHostToDevice, h->stream));
-    RCHK(enc_plan(h, h->enc_add, 1, H, W));
-    RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr));
-    const Tens& f = h->enc_add.c41;
-    float* keep = nullptr;
-    RCHK(dalloc(h, &keep, f.img_floats(), false));
-    HIPCHK(hipMemcpyAsync(keep, f.p, f.img_floats() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->patches.push_back(keep);
-    h->patch_h = f.H; h->patch_w = f.W; h->add_H = H; h->add_W = W;
+    const size_t fb = (size_t)H * W * 3;
+    if ((size_t)(h->pend_n + 1) * fb > h->pend_cap) {      // grow (x2) keeping the frames already collected
+        const size_t cap = ((size_t)(h->pend_n + 1) * fb) * 2 > 16 * fb ? ((size_t)(h->pend_n + 1) * fb) * 2 : 16 * fb;
+        uint8_t* nw = nullptr;
+        HIPCHK(hipMalloc((void**)&nw, cap));
+        if (h->pend_n) HIPCHK(hipMemcpy(nw, h->pend_u8, (size_t)h->pend_n * fb, hipMemcpyDeviceToDevice));
+        if (h->pend_u8) (void)hipFree(h->pend_u8);
+        h->pend_u8 = nw; h->pend_cap = cap;
+    }
+    HIPCHK(hipMemcpy(h->pend_u8 + (size_t)h->pend_n * fb, frame, fb, hipMemcpyHostToDevice));
+    h->pend_n += 1;
+    h->add_H = H; h->add_W = W;
     return RRV_OK;
 }
 
@@ -914,6 +944,7 @@ int rrv_compute(rrv_handle h) {
     if (!h) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
+    RCHK(flush_pending(h));
     if (h->patches.empty()) return fail(h, RRV_E_STATE, "compute: no frames added");
     int nprep = 0;
     for (StyleState& s : h->styles) nprep += s.prepared ? 1 : 0;
@@ -1143,6 +1174,7 @@ int rrv_add_patch(rrv_handle h, int feature_id) {
     if (!h || feature_id < 0 || feature_id >= (int)h->features.size() || !h->features[feature_id].p) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
+    RCHK(flush_pending(h));      // keeps the order of add() and add_patch() calls
     const rrv_ctx::Feature& ft = h->features[feature_id];
     if (!h->patches.empty() && (ft.H != h->add_H || ft.W != h->add_W))
         return fail(h, RRV_E_ARG, "add_patch: all sampled features must have the same size");
