@@ -1,0 +1,167 @@
+"""Command-line driver: the flow of the reference's test/generate_real_video.py (:86-186) on top of the HIP path.
+
+    python -m rerevst-code_amd.driver --style style.jpg --frames 'video/*.png' --checkpoint style_net-TIP-final.pth \
+           --out result_frames/name [--video result.avi --fps 24] [--no-global]
+
+Reads the style image and the content frames (PNG / JPEG, through Pillow; BGR uint8 arrays as cv2.imread gives the
+reference), runs prepare_style / clean / add (every 8th frame + the last, :129-143) / compute, stylizes every frame with
+pad + crop on the device (`Stylization.transfer_frames`), writes the stylized frames under the input file names
+(saturating float -> uint8 as cv2.imwrite does, :170-171) and optionally a Motion-JPEG AVI (:175-186).
+
+Differences from the reference script, on purpose: the frame list is sorted (the reference's comment asks for it, its
+code forgets the sort()); image decoding / encoding is Pillow's, not OpenCV's (neither is part of the measured path).
+"""
+import argparse
+import glob
+import io
+import os
+import struct
+import sys
+
+import numpy as np
+
+
+def _pil():
+    try:
+        from PIL import Image
+    except ImportError as e:                       # no silent fallback: the driver needs an image codec
+        raise RuntimeError("the driver needs Pillow for PNG/JPEG I/O") from e
+    return Image
+
+
+def read_image_bgr(path):
+    """uint8 [H][W][3] in BGR order, like cv2.imread(path) (generate_real_video.py:54-55)."""
+    with _pil().open(path) as im:
+        rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def to_uint8(img):
+    """cv2.imwrite's conversion of a float image: round to nearest, saturate to 0..255."""
+    if img.dtype == np.uint8:
+        return img
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def write_image_bgr(path, img):
+    """Write a BGR image (uint8, or float in 0..255) as cv2.imwrite(path, img) would; format from the extension."""
+    rgb = np.ascontiguousarray(to_uint8(img)[:, :, ::-1])
+    _pil().fromarray(rgb, "RGB").save(path)
+
+
+def list_frames(pattern):
+    """Sorted frame list of glob pattern `pattern` (generate_real_video.py:23-25, 102)."""
+    frames = sorted(glob.glob(pattern))
+    if not frames:
+        raise FileNotFoundError("no content frames match %r" % pattern)
+    return frames
+
+
+class MJPGWriter:
+    """Minimal Motion-JPEG AVI muxer (cv2.VideoWriter(..., fourcc('M','J','P','G'), fps, (W, H)), :179-186):
+    RIFF 'AVI ' = hdrl (avih + one video stream: strh/strf) + movi ('00dc' JPEG chunks) + idx1."""
+
+    def __init__(self, path, fps, width, height, quality=95):
+        self.path, self.fps, self.w, self.h, self.q = path, float(fps), int(width), int(height), int(quality)
+        self.f = open(path, "wb")
+        self.index = []          # (offset inside movi, size)
+        self.f.write(b"\0" * self._header_size())          # header is written at close, when the frame count is known
+        self.movi_start = self.f.tell()
+        self.f.write(b"LIST" + struct.pack("<I", 0) + b"movi")
+
+    @staticmethod
+    def _header_size():
+        return 12 + (8 + 4 + (8 + 56) + (8 + 4 + (8 + 56) + (8 + 40)))
+
+    def write(self, frame_bgr):
+        if frame_bgr.shape[0] != self.h or frame_bgr.shape[1] != self.w:
+            raise ValueError("frame size %r does not match the video size %r" % (frame_bgr.shape[:2], (self.h, self.w)))
+        buf = io.BytesIO()
+        _pil().fromarray(np.ascontiguousarray(to_uint8(frame_bgr)[:, :, ::-1]), "RGB").save(buf, "JPEG", quality=self.q)
+        data = buf.getvalue()
+        off = self.f.tell() - (self.movi_start + 8)
+        self.f.write(b"00dc" + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b""))
+        self.index.append((off, len(data)))
+
+    def release(self):
+        n = len(self.index)
+        movi_end = self.f.tell()
+        idx = b"".join(b"00dc" + struct.pack("<III", 0x10, off, size) for off, size in self.index)
+        self.f.write(b"idx1" + struct.pack("<I", len(idx)) + idx)
+        end = self.f.tell()
+        usec = int(round(1e6 / self.fps))
+        max_bytes = max((s for _, s in self.index), default=0)
+        avih = struct.pack("<IIIIIIIIIIIIII", usec, int(max_bytes * self.fps), 0, 0x10, n, 0, 1, max_bytes, self.w, self.h, 0, 0, 0, 0)
+        rate, scale = (int(round(self.fps * 1000)), 1000)
+        strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIIIhhhh", 0, 0, 0, 0, scale, rate, 0, n, max_bytes, 0xFFFFFFFF, 0, 0, 0, self.w, self.h)
+        strf = struct.pack("<IiiHHIIiiII", 40, self.w, self.h, 1, 24, 0x47504A4D, self.w * self.h * 3, 0, 0, 0, 0)   # BITMAPINFOHEADER, 'MJPG'
+        strl = b"LIST" + struct.pack("<I", 4 + 8 + len(strh) + 8 + len(strf)) + b"strl" + b"strh" + struct.pack("<I", len(strh)) + strh + \
+               b"strf" + struct.pack("<I", len(strf)) + strf
+        hdrl = b"LIST" + struct.pack("<I", 4 + 8 + len(avih) + len(strl)) + b"hdrl" + b"avih" + struct.pack("<I", len(avih)) + avih + strl
+        head = b"RIFF" + struct.pack("<I", end - 8) + b"AVI " + hdrl
+        assert len(head) == self._header_size(), (len(head), self._header_size())
+        self.f.seek(0)
+        self.f.write(head)
+        self.f.seek(self.movi_start + 4)
+        self.f.write(struct.pack("<I", movi_end - self.movi_start - 8))
+        self.f.close()
+
+
+def stylize_files(model, style_path, frame_paths, out_dir, video_path=None, fps=24, chunk=32, log=print):
+    """The reference script's main flow for one style and one frame list; returns the written frame paths."""
+    video = __import__("importlib").import_module("rerevst-code_amd.video")
+    os.makedirs(out_dir, exist_ok=True)
+    model.prepare_style(read_image_bgr(style_path))
+    n = len(frame_paths)
+    if getattr(model, "use_Global", True):
+        log("Preparations for Sequence-Level Global Feature Sharing (%d sampled frames)" % len(video.sample_indices(n)))
+        model.clean()
+        for i in video.sample_indices(n):
+            model.add(read_image_bgr(frame_paths[i]))
+        model.compute()
+    written, writer = [], None
+    for c0 in range(0, n, chunk):
+        idx = range(c0, min(n, c0 + chunk))
+        frames = [read_image_bgr(frame_paths[i]) for i in idx]
+        on_device = getattr(model, "transfer_frames", None)              # absent on a model with the reference's surface only
+        if on_device is not None and getattr(model, "use_Global", True) and all(f.shape == frames[0].shape for f in frames):
+            styled = on_device(frames)                                   # pad + crop on the device
+        else:
+            tool = video.ReshapeTool()
+            styled = [model.transfer(tool.process(f))[64:64 + f.shape[0], 64:64 + f.shape[1], :] for f in frames]
+        for j, i in enumerate(idx):
+            out_path = os.path.join(out_dir, os.path.basename(frame_paths[i]))
+            write_image_bgr(out_path, styled[j])
+            written.append(out_path)
+            if video_path:
+                if writer is None:
+                    writer = MJPGWriter(video_path, fps, styled[j].shape[1], styled[j].shape[0])
+                writer.write(styled[j])
+        log("stylized frames %d..%d of %d" % (idx[0], idx[-1], n))
+    if writer is not None:
+        writer.release()
+    return written
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--style", required=True)
+    ap.add_argument("--frames", required=True, help="glob pattern of the content frames")
+    ap.add_argument("--checkpoint", required=True, help="style_net-TIP-final.pth (or 'synthetic' for seeded weights)")
+    ap.add_argument("--out", required=True, help="directory for the stylized frames")
+    ap.add_argument("--video", default=None, help="also write a Motion-JPEG .avi here")
+    ap.add_argument("--fps", type=float, default=24)
+    ap.add_argument("--no-global", action="store_true", help="per-frame statistics (use_Global=False)")
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args(argv)
+    if not os.path.exists(args.style):
+        sys.exit("Style image %s not exists" % args.style)            # generate_real_video.py:93-94
+    pkg = __import__("importlib").import_module("rerevst-code_amd")
+    ckpt = pkg.synthetic_weights(0) if args.checkpoint == "synthetic" else args.checkpoint
+    model = pkg.Stylization(ckpt, cuda=True, use_Global=not args.no_global, device=args.device)
+    stylize_files(model, args.style, list_frames(args.frames), args.out, args.video, args.fps)
+    model.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""Host-side driver (rerevst-code_amd/driver.py): image I/O conventions of cv2.imread / cv2.imwrite, the sorted frame
+list, the Motion-JPEG AVI container, and the reference script's flow (test/generate_real_video.py:86-186) end to end
+with the CPU oracle standing in for the GPU model."""
+import importlib
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+
+D = importlib.import_module("rerevst-code_amd.driver")
+Image = pytest.importorskip("PIL.Image")
+
+
+def test_png_roundtrip_is_bgr_and_exact(tmp_path):
+    img = np.random.default_rng(0).integers(0, 256, (13, 17, 3), dtype=np.uint8)     # BGR
+    p = str(tmp_path / "a.png")
+    D.write_image_bgr(p, img)
+    np.testing.assert_array_equal(D.read_image_bgr(p), img)
+    with Image.open(p) as im:                                                         # the file itself holds RGB
+        np.testing.assert_array_equal(np.asarray(im), img[:, :, ::-1])
+
+
+def test_float_images_saturate_and_round_like_imwrite(tmp_path):
+    f = np.array([[[-3.0, 0.49, 0.5], [254.5, 255.4, 300.0]]], dtype=np.float32)
+    np.testing.assert_array_equal(D.to_uint8(f), np.array([[[0, 0, 0], [254, 255, 255]]], dtype=np.uint8))   # rint: ties to even
+    p = str(tmp_path / "f.png")
+    D.write_image_bgr(p, np.full((4, 4, 3), 127.6, np.float32))
+    assert (D.read_image_bgr(p) == 128).all()
+
+
+def test_frame_list_is_sorted_and_missing_pattern_fails(tmp_path):
+    for n in ("frame_0010.png", "frame_0002.png", "frame_0001.png"):
+        D.write_image_bgr(str(tmp_path / n), np.zeros((4, 4, 3), np.uint8))
+    assert [os.path.basename(p) for p in D.list_frames(str(tmp_path / "*.png"))] == ["frame_0001.png", "frame_0002.png", "frame_0010.png"]
+    with pytest.raises(FileNotFoundError):
+        D.list_frames(str(tmp_path / "*.jpg"))
+
+
+def test_mjpg_avi_container(tmp_path):
+    p = str(tmp_path / "v.avi")
+    w = D.MJPGWriter(p, 24, 32, 20)
+    frames = [np.full((20, 32, 3), v, np.uint8) for v in (10, 120, 240)]
+    for f in frames:
+        w.write(f)
+    with pytest.raises(ValueError):
+        w.write(np.zeros((8, 8, 3), np.uint8))
+    w.release()
+    b = open(p, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"AVI " and struct.unpack("<I", b[4:8])[0] == len(b) - 8
+    assert b[12:16] == b"LIST" and b[20:24] == b"hdrl" and b[24:28] == b"avih"
+    usec, _, _, flags, nframes, _, nstreams, _, width, height = struct.unpack("<10I", b[32:72])
+    assert (usec, flags & 0x10, nframes, nstreams, width, height) == (41667, 0x10, 3, 1, 32, 20)
+    assert b[108:112] == b"vids" and b[112:116] == b"MJPG"
+    movi = b.index(b"movi")
+    assert b[movi + 4:movi + 8] == b"00dc"
+    size = struct.unpack("<I", b[movi + 8:movi + 12])[0]
+    with Image.open(io.BytesIO(b[movi + 12:movi + 12 + size])) as im:                 # the first chunk is a JPEG of frame 0
+        a = np.asarray(im.convert("RGB"))
+    assert a.shape == (20, 32, 3) and abs(int(a.mean()) - 10) <= 2
+    idx = b.index(b"idx1")
+    assert struct.unpack("<I", b[idx + 4:idx + 8])[0] == 3 * 16
+    ck, fl, off, sz = struct.unpack("<4sIII", b[idx + 8:idx + 24])
+    assert (ck, fl, off, sz) == (b"00dc", 0x10, 4, size)
+
+
+def test_reference_script_flow_with_the_oracle(tmp_path, pkg, oracle):
+    """prepare_style -> clean -> add(sampled) -> compute -> transfer(pad) -> crop -> write, on files."""
+    src, out = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    frames = [pkg.synth_frame(i, 24, 32, kind="smooth") for i in range(3)]
+    for i, f in enumerate(frames):
+        D.write_image_bgr(str(src / ("f%02d.png" % i)), f)
+    D.write_image_bgr(str(tmp_path / "style.png"), pkg.synth_style(32, 32, kind="smooth"))
+    model = oracle.Stylization(pkg.synthetic_weights(0))
+    written = D.stylize_files(model, str(tmp_path / "style.png"), D.list_frames(str(src / "*.png")), str(out),
+                              video_path=str(tmp_path / "v.avi"), fps=12, log=lambda *_: None)
+    assert [os.path.basename(p) for p in written] == ["f00.png", "f01.png", "f02.png"]
+    V = importlib.import_module("rerevst-code_amd.video")
+    ref_model = oracle.Stylization(pkg.synthetic_weights(0))
+    ref = V.stylize_video(ref_model, frames, pkg.synth_style(32, 32, kind="smooth"))
+    for i, p in enumerate(written):
+        got = D.read_image_bgr(p)
+        assert got.shape == (24, 32, 3)
+        np.testing.assert_array_equal(got, D.to_uint8(ref[i]))
+    assert os.path.getsize(str(tmp_path / "v.avi")) > 212
