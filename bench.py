@@ -220,6 +220,21 @@ def main():
                                       % (NF, S, S, P, P), "frames_per_step_per_gpu": B, "batches_in_flight": args.pipeline, "sampled_frames": len(video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
                "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu, "prep_seconds_rank0": round(prep_s, 3), "kernels": kern}
+        if world == 1:
+            # extra, NOT `value`: the driver-level entry on the same frames — unpadded frames in HBM in, cropped frames in
+            # HBM out (rrv_transfer_frames_device: reflect padding and crop inside the first / last kernel, and the
+            # full-resolution layers compute only the tiles the crop window needs).  Same delivered pixels, less work.
+            raw = torch.from_numpy(np.stack([pkg.synth_frame(i, S, S, kind="noise") for i in my_ids[:2 * B]])).to(dev).view(2, B, S, S, 3)
+            d_crop = torch.empty((4, B, S, S, 3), dtype=torch.float32, device=dev)
+            nrep = max(4, min(20, args.steps))
+            for i in range(2):
+                model.transfer_frames_device(raw[i % 2].data_ptr(), B, S, S, d_crop[i & 3].data_ptr())
+            model.sync(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(nrep):
+                model.transfer_frames_device(raw[i % 2].data_ptr(), B, S, S, d_crop[i & 3].data_ptr())
+            model.sync(); torch.cuda.synchronize()
+            out["cropped_entry_frames_per_s"] = round(nrep * B / (time.perf_counter() - t1), 1)
         if os.environ.get("RRV_BENCH_LAYERS"):
             out["layers"] = [{"layer": k, "ms_per_frame": round(v[1] / nprof / B, 4), "tflops": round(v[2] / v[1] / 1e9, 1),
                               "tflops_executed": round(v[3] / v[1] / 1e9, 1)}

@@ -61,6 +61,7 @@ struct ConvP {
     int tiles_x, tiles_y;
     int xcd_slabs;     // conv_wino_k: co-locate the cout slabs of a pixel tile on one XCD (see conv_wino.h)
     float* sc_out;     // conv_wino_k<.., UPS = 1, SC = 1>: low-resolution output of the fused 1x1 shortcut [B,Hi,Wi,Cout] (ring layout)
+    int ty0, tx0;      // transform-domain kernels: first tile row / column of the output window (tiles_x, tiles_y count its tiles)
 };
 
 template <int BN>

@@ -160,6 +160,7 @@ struct LastP {
     // optional on-device crop (generate_real_video.py:167): out_img is [B][out_H][out_W][3] and receives the window
     // that starts at (crop_top, crop_left) of the padded frame.  out_H == 0: the whole padded frame.
     int out_H, out_W, crop_top, crop_left;
+    int ty0, tx0;         // first tile row / column of the computed window (tiles_x, tiles_y count its tiles)
 };
 
 // Matrix-core form: v_mfma_f32_4x4x1_16B_f32 runs 16 independent 4x4 outer products per instruction
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
     const int tx = bx % p.tiles_x;
     bx /= p.tiles_x;
     const int ty = bx % p.tiles_y, b = bx / p.tiles_y;
-    const int y0 = ty * 16, x0 = tx * 16;
+    const int y0 = (ty + p.ty0) * 16, x0 = (tx + p.tx0) * 16;
     const float* in_b = p.in + (size_t)b * (size_t)(p.H + 2) * (p.W + 2) * 64;
 
     auto stage = [&](int chunk, int buf) {

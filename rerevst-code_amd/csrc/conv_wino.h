@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     // scalar bases of an item: its input tile origin (the per-thread halo offsets asrc[] are tile-relative and
     // never change) and its U slab
     auto in_of = [&](const Item& a) {
-        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)((a.ty * G::TIN) * (p.Wi + 2) + a.tx * G::TIN) * p.Cin;
+        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)(((a.ty + p.ty0) * G::TIN) * (p.Wi + 2) + (a.tx + p.tx0) * G::TIN) * p.Cin;
     };
     auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NPU * 32 * 16); };
     int asrc[G::RAW_IT];
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         for (int r = 0; r < PW; ++r) row_pass(va, r);
     }
     while (have) {
-        const int e_y0 = cur.ty * 16, e_x0 = cur.tx * 16, e_b = cur.b, e_ntile = cur.nt;
+        const int e_y0 = (cur.ty + p.ty0) * 16, e_x0 = (cur.tx + p.tx0) * 16, e_b = cur.b, e_ntile = cur.nt;
         nxt = advance(cur);
         have_nxt = nxt.b < p.B;
         in_n = have_nxt ? in_of(nxt) : in_t;      // no next item: the last two chunks re-request this item's first tiles

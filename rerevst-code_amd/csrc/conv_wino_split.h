@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         return r;
     };
     auto in_of = [&](const Item& a) {
-        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)((a.ty * 16) * (p.Wi + 2) + a.tx * 16) * p.Cin;
+        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)(((a.ty + p.ty0) * 16) * (p.Wi + 2) + (a.tx + p.tx0) * 16) * p.Cin;
     };
     auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (16 * 32 * 16); };
     int asrc[G::RAW_IT];
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         for (int rl = 0; rl < 2; ++rl) row_pass(va, rl);
     }
     while (have) {
-        const int e_y0 = cur.ty * 16, e_x0 = cur.tx * 16, e_b = cur.b, e_ntile = cur.nt;
+        const int e_y0 = (cur.ty + p.ty0) * 16, e_x0 = (cur.tx + p.tx0) * 16, e_b = cur.b, e_ntile = cur.nt;
         nxt = advance(cur);
         have_nxt = nxt.b < p.B;
         in_n = have_nxt ? in_of(nxt) : in_t;      // no next item: the last two chunks re-request this item's first tiles

@@ -189,6 +189,7 @@ struct ConvCall {
     int H, W;                 // convolution resolution
     bool ups = false; int epi = 0;
     Tens* sc_out = nullptr;   // ups only: also produce the fused 1x1 shortcut (needs w->pk_ups_sc)
+    int wy0 = 0, wx0 = 0, wy1 = 0, wx1 = 0;   // transform-domain kernels: compute only output rows [wy0,wy1) x columns [wx0,wx1) (multiples of 16; all 0 = everything)
     const float* n1 = nullptr; const Tens* res = nullptr; const float* n2 = nullptr; const float* sty = nullptr;
     int B = 1;
 };
@@ -279,6 +280,13 @@ int conv(rrv_handle h, const ConvCall& c) {
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
     if (c.out->H != oh || c.out->W != ow) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
     if (wino) { p.tiles_y = (c.H + 15) / 16; }
+    double win_frac = 1.0;
+    if (wino && c.wy1 > c.wy0 && c.wx1 > c.wx0) {      // output window (on-device crop: nothing outside it is ever read)
+        if ((c.wy0 | c.wx0 | c.wy1 | c.wx1) & 15) return fail(h, RRV_E_ARG, "conv: window must be tile aligned");
+        p.ty0 = c.wy0 / 16; p.tx0 = c.wx0 / 16;
+        p.tiles_y = (c.wy1 - c.wy0) / 16; p.tiles_x = (c.wx1 - c.wx0) / 16;
+        win_frac = ((double)(c.wy1 - c.wy0) * (c.wx1 - c.wx0)) / ((double)((c.H + 15) / 16 * 16) * ((c.W + 15) / 16 * 16));
+    }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B), (unsigned)(w.Cout / w.BN));
     if (wino) {   // persistent workgroups (one per CU; two for the upsample-fused form), walking tiles_x*tiles_y*B*(Cout/32) work items
         const unsigned slabs = (unsigned)(w.Cout / 32);
@@ -288,7 +296,7 @@ int conv(rrv_handle h, const ConvCall& c) {
         // slabs of one pixel tile on one XCD (workgroup w runs on XCD w % 8): the raw tile is fetched once per XCD group
         p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
     }
-    const double px = (double)c.B * c.H * c.W;
+    const double px = (double)c.B * c.H * c.W * win_frac;
     // algorithmic FLOPs = the reference's direct convolution (taps multiply-adds per output);
     // executed: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 outputs (4 per pixel), the upsample-fused form 9 (2.25 per pixel)
     // (a fused shortcut adds its own 1x1 conv at the input resolution: one more GEMM position, 2.5 per output pixel)
@@ -521,23 +529,30 @@ int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {
     return RRV_OK;
 }
 
-int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens& a, Tens& o, int n1, int n2, int nada, int sty) {
+struct Win { int y0, x0, y1, x1; };     // output window in pixels, tile aligned; y1 == 0: everything
+
+int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens& a, Tens& o, int n1, int n2, int nada, int sty,
+                   const Win* wa = nullptr, const Win* wo = nullptr) {
     const float* st = h->active;
     const std::string p = std::string("Decoder.") + blk;
     ConvCall c;
     // conv1 behind the upsample and, in the same kernel, the 1x1 shortcut at the input resolution: up(conv1x1(x)) == conv1x1(up(x))
     c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.B = in.B; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1];
-    c.sc_out = &xs; RCHK(conv(h, c));
+    c.sc_out = &xs;
+    if (wa) { c.wy0 = wa->y0; c.wx0 = wa->x0; c.wy1 = wa->y1; c.wx1 = wa->x1; }
+    RCHK(conv(h, c));
     c = ConvCall{&a, &o, &h->conv[p + ".conv2"], a.H, a.W}; c.B = in.B;
     c.epi = E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2; c.n1 = st + SL.norm[n2]; c.res = &xs; c.n2 = st + SL.norm[nada]; c.sty = st + SL.sty[sty];
+    if (wo) { c.wy0 = wo->y0; c.wx0 = wo->x0; c.wy1 = wo->y1; c.wx1 = wo->x1; }
     RCHK(conv(h, c));
     return RRV_OK;
 }
 
 // Decoder.slice1 + transform_back_image (conv_last_k) on a normalised slice2 output
-int run_last(rrv_handle h, const Tens& o2, int B, int H, int W, float* d_out, float* pre, const PadCrop* pc) {
+int run_last(rrv_handle h, const Tens& o2, int B, int H, int W, float* d_out, float* pre, const PadCrop* pc, const Win* wl = nullptr) {
     LastP lp{o2.p, H, W, B, h->last_w, h->last_b, d_out, pre, (W + 15) / 16, (H + 15) / 16,
-             pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
+             pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0, 0, 0};
+    if (wl) { lp.ty0 = wl->y0 / 16; lp.tx0 = wl->x0 / 16; lp.tiles_y = (wl->y1 - wl->y0) / 16; lp.tiles_x = (wl->x1 - wl->x0) / 16; }
     h->last_pre = pre; h->last_pre_H = H; h->last_pre_W = W;
     return launch(h, "conv_last", 2.0 * B * H * W * 576 * 3, (256.0 + 12.0) * B * H * W, [&] {
         hipLaunchKernelGGL(conv_last_k, dim3(lp.tiles_x * lp.tiles_y * B), dim3(256), 0, h->stream, lp);
@@ -582,8 +597,24 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     }
     RCHK(resblock_frame(h, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2));
     RCHK(resblock_frame(h, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1));
-    RCHK(resblock_frame(h, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0));
-    RCHK(run_last(h, d.o2, B, H, W, d_out, d.pre, pc));
+    // On-device crop: nothing outside the crop window is delivered, so the full-resolution layers only compute the
+    // tiles the window (plus one halo pixel per 3x3 layer) needs; results inside the window are unchanged.  One level
+    // down (320^2) the tile-rounded window already covers the frame for the reference's 64-pixel pad.
+    Win wl{0, 0, 0, 0}, wo{0, 0, 0, 0}, wa{0, 0, 0, 0};
+    const bool roi = pc != nullptr;
+    if (roi) {
+        auto grow = [&](const Win& w, int halo) {
+            auto lo = [&](int v) { v -= halo; return v < 0 ? 0 : (v & ~15); };
+            auto hi = [&](int v, int lim) { v = (v + halo + 15) & ~15; const int l = (lim + 15) & ~15; return v > l ? l : v; };
+            return Win{lo(w.y0), lo(w.x0), hi(w.y1, H), hi(w.x1, W)};
+        };
+        const Win crop{pc->top, pc->left, pc->top + pc->src_H, pc->left + pc->src_W};
+        wl = grow(crop, 0);        // conv_last output tiles
+        wo = grow(crop, 1);        // slice2.conv2 output feeding them
+        wa = grow(wo, 1);          // slice2.conv1 output (and, halved, the shortcut) feeding that
+    }
+    RCHK(resblock_frame(h, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr));
+    RCHK(run_last(h, d.o2, B, H, W, d_out, d.pre, pc, roi ? &wl : nullptr));
     return RRV_OK;
 }
 
