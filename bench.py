@@ -1,19 +1,33 @@
 #!/usr/bin/env python
-"""Throughput bench of the per-frame stylization path (BASELINE.json metric:
-stylized frames/sec at 512x512, 1 style).
+"""Throughput bench of the per-frame stylization path (BASELINE.json metric: stylized frames/sec at
+512x512, 1 style; 1/2/4/8 MI355X + CPU ref).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--size 256|512|1024] [--multistyle S]
 
-A step = one pass of the per-frame path over one batch of `--batch` 512x512 synthetic frames
-(reflect-padded to 640x640 as generate_real_video.py:61-83 does) per GPU, uint8 frames resident
-in HBM -> float32 BGR frames in HBM.  N>1: one process per GPU (torch.distributed / RCCL), rank 0 runs prepare_style +
-add + compute and broadcasts the 70 KB shared state; frames are sharded, no per-frame
-communication ("weak" scaling: every rank stylizes K frames).  Prints ONE JSON line.
+`value` is HOST -> HOST, as SURVEY.md §8(d) defines the metric and as the reference's transfer() works
+(test/framework.py:109 `.to(device)` ... :40 `.cpu()`): a step = one `rrv_transfer_batch` call over `--batch`
+synthetic SxS frames per GPU (reflect-padded to P = roundup64(S+128) as generate_real_video.py:61-83 does), uint8
+frames in (page-locked) host memory -> float32 BGR frames in (page-locked) host memory; the sub-batches of 8 are
+pipelined inside the call (H2D / kernels / D2H on two HIP streams).  Extras, never `value`: the HBM -> HBM rate of
+the same frames (`device_resident_frames_per_s`), the rate with pageable caller arrays, and the unpadded-in /
+cropped-out entry.
+
+--multistyle S (BASELINE config 5, default size 1024): the "Multi-style Interpolation" flow — encoder features of
+every frame cached in HBM (test.py:87-101), statistics from every 16th + the last (:72-85), then per frame the DECODER
+ONLY with the S-style blended state and the reference's weight ramp (:127-131); a step = `--batch` frames, feature in
+HBM -> float32 frame in host memory.
+
+N > 1: one process per GPU.  Started plainly (`python bench.py --gpus N`) the script launches its N ranks itself;
+under torch.distributed.run it uses the ranks it is given.  Rank 0 runs prepare_style + add + compute and broadcasts
+the 70 KB state blob per style (RCCL); frames are sharded, no per-frame communication ("weak" scaling: every rank
+stylizes steps x batch frames).  Prints ONE JSON line (rank 0).
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,9 +36,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
 EPI_BITS = {"E_RELU": 1, "E_LRELU": 2, "E_NORM1": 4, "E_RES": 8, "E_RES_UPS": 16, "E_NORM2": 32, "E_POOL": 64}
+HBM_KERNELS = ("conv_first", "conv_last")      # the two thin ends of the path are HBM-bound, everything else MFMA-bound
 
 
 def rocprof_name(kernel):
@@ -47,8 +62,11 @@ def rocprof_name(kernel):
     return kernel
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/hbm_traffic.json), or None."""
+def measured_traffic(kernel, size=512):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/hbm_traffic.json: 512x512, 8 frames per
+    launch), or None (other sizes have no committed pass)."""
+    if size != 512:
+        return None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             t = json.load(f)
@@ -61,18 +79,139 @@ def measured_traffic(kernel):
         return None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
+
+
+def roofline_and_kernels(rows, nprof, frames_per_step, size):
+    """Per-kernel aggregation of the live HIP-event rows of the profiled steps and the roofline of the dominant one.
+    `frac` = EXECUTED FLOPs / event time / fp32-MFMA peak (what the matrix pipe actually issues); the reference's
+    direct-convolution FLOPs over the same time is `algorithmic_tflops` (the transform-domain kernels need 2.25x /
+    4x fewer multiplies, so it may exceed the peak) and their ratio `algorithmic_speedup`."""
+    agg, layers = {}, {}
+    for full, ms, fl, by, fx in rows:
+        name = full.split("@")[0]
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by; a[4] += fx
+        if "@" in full:
+            l = layers.setdefault(full, [0, 0.0, 0.0, 0.0])
+            l[0] += 1; l[1] += ms; l[2] += fl; l[3] += fx
+    if not agg:
+        return None, [], {}
+    kern = []
+    tot_ms = sum(a[1] for a in agg.values())
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        hbm = name.startswith(HBM_KERNELS) or name in ("pointwise", "chan_stat", "chan_final")
+        k = {"kernel": name, "launches_per_step": a[0] / nprof, "ms_per_frame": round(a[1] / nprof / frames_per_step, 4),
+             "bound": "hbm" if hbm else "mfma"}
+        if a[1] > 0 and a[3] > 0:
+            k["gbs"] = round(a[3] / a[1] / 1e6, 1)
+        if a[1] > 0 and a[2] > 0 and not hbm:
+            k["tflops_executed"] = round(a[4] / a[1] / 1e9, 2)
+            k["frac_of_mfma_peak"] = round(a[4] / a[1] / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)
+            k["tflops_algorithmic"] = round(a[2] / a[1] / 1e9, 2)
+        if a[1] > 0 and hbm and a[3] > 0:
+            k["frac_of_hbm_peak"] = round(a[3] / a[1] / 1e6 / PEAK_HBM_GBS, 4)
+        kern.append(k)
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    n, t_ms, fl, by, fx = dom[1]
+    executed = fx / t_ms / 1e9
+    mf = [a for nm, a in agg.items() if nm.startswith(("conv_mfma", "conv_wino", "conv_upw"))]
+    roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": measured_traffic(dom[0], size),
+            "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 8 frames per "
+                              "launch; bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024)",
+            "algorithmic_bytes_per_launch": round(by / n),
+            "algorithmic_tflops": round(fl / t_ms / 1e9, 2), "algorithmic_speedup": round(fl / fx, 3),
+            "note": "achieved/frac = FLOPs the kernel EXECUTES / HIP-event time / fp32-MFMA peak; algorithmic_tflops = FLOPs of "
+                    "the reference's direct 3x3 convolution over the same time (transform-domain kernels multiply 2.25x-4x less)",
+            "avg_launch_ms": round(t_ms / n, 5), "share_of_gpu_time": round(t_ms / tot_ms, 3),
+            "all_matrix_kernels_executed_tflops": round(sum(a[4] for a in mf) / sum(a[1] for a in mf) / 1e9, 2),
+            "all_matrix_kernels_executed_frac": round(sum(a[4] for a in mf) / sum(a[1] for a in mf) / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+            "all_matrix_kernels_algorithmic_tflops": round(sum(a[2] for a in mf) / sum(a[1] for a in mf) / 1e9, 2)}
+    return roof, kern, layers
+
+
+def cpu_baseline(setup, unit, what, budget_s=25.0):
+    """The CPU port (oracle/rerevst_oracle.py with its convolutions on torch's CPU conv2d = the reference's own
+    primitive), timed on this box's host cores on a bounded sample: median of 5 frames with all cores after one
+    warm-up, then a 1-core run (3 frames, or 2 when they are slow).  setup(O) -> (make_input(k), run(x))."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rerevst_oracle as O      # checker / timed CPU port only
+    O.set_conv_backend("torch")
+    make_input, run = setup(O)
+    ncores = os.cpu_count() or 1
+    res = {}
+    for label, nthreads, nmin in (("all", min(ncores, 64), 5), ("one", 1, 3)):
+        torch.set_num_threads(nthreads)
+        ctx = None
+        try:
+            from threadpoolctl import threadpool_limits
+            ctx = threadpool_limits(limits=nthreads)
+        except Exception:
+            pass
+        if label == "all":
+            run(make_input(0))                        # warm-up
+        ts, t_tot, k = [], 0.0, 1
+        while len(ts) < nmin:
+            x = make_input(k)
+            t0 = time.perf_counter()
+            run(x)
+            ts.append(time.perf_counter() - t0)
+            t_tot += ts[-1]
+            k += 1
+            if label == "one" and t_tot > budget_s and len(ts) >= 2:
+                break
+        if ctx is not None:
+            ctx.restore_original_limits()
+        res[label] = (statistics.median(ts), len(ts), nthreads)
+    torch.set_num_threads(min(ncores, 64))
+    O.set_conv_backend("numpy")
+    med, n, thr = res["all"]
+    med1, n1, _ = res["one"]
+    return {"value": round(1.0 / med, 4), "unit": unit, "cores": thr, "kind": "port",
+            "sample": "median of %d %s through oracle/rerevst_oracle.py (fp32, convolutions on torch CPU conv2d = the reference's "
+                      "primitive; %d threads of %d host cores) after 1 warm-up" % (n, what, thr, ncores),
+            "one_core_value": round(1.0 / med1, 4), "one_core_sample": "median of %d, 1 thread" % n1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
-    ap.add_argument("--size", type=int, default=512, help="frame side (256/512/1024)")
-    ap.add_argument("--frames", type=int, default=300, help="frames of the synthetic video")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 64 at 512x512, scaled with the frame area)")
+    ap.add_argument("--size", type=int, default=0, help="frame side: 256 / 512 / 1024 (default 512; 1024 with --multistyle)")
+    ap.add_argument("--frames", type=int, default=0, help="frames of the synthetic video (default: BASELINE configs, 100 / 300 / 300)")
+    ap.add_argument("--multistyle", type=int, default=0, help="S > 0: BASELINE config 5, S-style interpolation, decoder only per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=4)
-    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight per GPU (1 or 2 HIP streams)")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--pipeline", type=int, default=2, help="sub-batches in flight per GPU (1 or 2 HIP streams)")
+    ap.add_argument("--pageable", action="store_true", help="time the host entry with pageable caller arrays instead of page-locked ones")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -83,75 +222,111 @@ def main():
     # RRV_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a 1-GPU box (all ranks on GPU 0)
     backend = os.environ.get("RRV_BENCH_BACKEND", "nccl")
     local = local % max(1, torch.cuda.device_count())
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective payloads live
 
     pkg = importlib.import_module("rerevst-code_amd")
     video = importlib.import_module("rerevst-code_amd.video")
-    S, NF = args.size, args.frames
+    NS = args.multistyle
+    S = args.size or (1024 if NS else 512)
+    NF = args.frames or {256: 100}.get(S, 300)
     P = video.padded_size(S)
-
+    B = args.batch or max(8, min(128, (64 * 640 * 640) // (P * P) // 8 * 8))
     weights = pkg.synthetic_weights(0)
-    model = pkg.Stylization(weights, cuda=True, device=local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    if NS:
+        model = pkg.MultiStyleStylization(weights, cuda=True, style_num=NS, device=local)
+    else:
+        model = pkg.Stylization(weights, cuda=True, device=local)
     model.set_pipeline(args.pipeline)
 
-    # ---- synthetic video: this rank's shard, padded, resident in HBM --------------------
-    B = args.batch
-    n_batches = max(1, min(NF // B, args.steps))          # distinct batches kept resident
-    first = (rank * args.steps * B) % NF
-    my_ids = [(first + i) % NF for i in range(n_batches * B)]
-    host = np.stack([video.reflect_pad(pkg.synth_frame(i, S, S, kind="noise"), P, P) for i in my_ids])
-    d_frames = torch.from_numpy(host).to(dev).view(n_batches, B, P, P, 3)
-    d_out = torch.empty((4, B, P, P, 3), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
-
     # ---- once-per-video preparation on rank 0, state broadcast over RCCL ------------------
+    first = (rank * args.steps * B) % NF                       # this rank's shard of the (cyclic) video
     t0 = time.time()
-    blob = torch.empty(17536, dtype=torch.float32, device=cdev)
-    if rank == 0:
-        model.prepare_style(pkg.synth_style(512, 512, kind="noise", seed=7))
-        model.clean()
-        for i in video.sample_indices(NF):
-            model.add(pkg.synth_frame(i, S, S, kind="noise"))      # unpadded (generate_real_video.py:139-143)
-        model.compute()
-        blob.copy_(torch.from_numpy(model.get_state()))
+    blob = torch.empty(max(1, NS) * 17536, dtype=torch.float32, device=cdev)
+    feats = None
+    if NS:
+        # features of this rank's frames, cached in HBM (rank 0 also needs the sampled ones for the statistics)
+        n_cached = min(NF, args.steps * B + args.warmup * B)
+        my_ids = [(first + i) % NF for i in range(n_cached)]
+        styles = [video.resize_bilinear(pkg.synth_style(512, 512, kind="noise", seed=7 + k), (384, 384)) for k in range(NS)]   # test.py:53
+        if rank == 0:
+            model.prepare_style(styles)
+            model.clean()
+            for i in video.sample_indices_multistyle(NF, 16):
+                f = model.generate_content_features(video.reflect_pad(pkg.synth_frame(i, S, S, kind="noise"), P, P))   # padded BEFORE encoding (test.py:96)
+                model.add_patch(f)
+            model.compute_norm()
+            model.release_features()
+            blob.copy_(torch.from_numpy(np.concatenate([model.get_state(k) for k in range(NS)])))
+        t1 = time.time()
+        feats = [model.generate_content_features(video.reflect_pad(pkg.synth_frame(i, S, S, kind="noise"), P, P)) for i in my_ids]
+        cache_s = time.time() - t1
+    else:
+        if rank == 0:
+            model.prepare_style(pkg.synth_style(512, 512, kind="noise", seed=7))
+            model.clean()
+            for i in video.sample_indices(NF):
+                model.add(pkg.synth_frame(i, S, S, kind="noise"))      # unpadded (generate_real_video.py:139-143)
+            model.compute()
+            blob.copy_(torch.from_numpy(model.get_state()))
     prep_s = time.time() - t0
     if world > 1:
         dist.broadcast(blob, src=0)
         if rank != 0:
-            model.set_state(blob.cpu().numpy())
+            b = blob.cpu().numpy()
+            for k in range(max(1, NS)):
+                model.set_state(b[k * 17536:(k + 1) * 17536], k)
 
-    def step(i):
-        model.transfer_batch_device(d_frames[i % n_batches].data_ptr(), B, P, P, d_out[i & 3].data_ptr())
+    # ---- this rank's frames / outputs in page-locked host memory (or pageable with --pageable) -----------
+    alloc = (lambda shp, dt: np.empty(shp, dt)) if args.pageable else pkg.pinned_empty
+    h_out = alloc((2, B, P, P, 3), np.float32)
+    if NS:
+        nW = len(feats)
+        def step(i):
+            o = h_out[i & 1]
+            for j in range(B):
+                k = i * B + j
+                g = (first + k) % NF                     # global frame index -> the reference's weight ramp
+                model.transfer(feats[k % nW], video.ramp_weights(g, NF, NS), out=o[j])
+    else:
+        n_batches = max(1, min(max(1, NF // B), args.steps))          # distinct batches kept resident in host memory
+        my_ids = [(first + i) % NF for i in range(n_batches * B)]
+        h_in = alloc((n_batches, B, P, P, 3), np.uint8)
+        for k, i in enumerate(my_ids):
+            h_in[k // B, k % B] = video.reflect_pad(pkg.synth_frame(i, S, S, kind="noise"), P, P)
+        def step(i):
+            model.transfer_batch(h_in[i % n_batches], out=h_out[i & 1])
 
     for i in range(args.warmup):
         step(i)
     model.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     nprof = max(0, min(args.profile_steps, args.steps))
     t0 = time.perf_counter()
     for i in range(args.steps - nprof):
         step(i)
+    rows = []
     if nprof:
         model.profile_begin()          # HIP events on the library's own stream, inside the timed region
         for i in range(args.steps - nprof, args.steps):
             step(i)
         rows = model.profile_end()
-    else:
-        rows = []
     model.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -159,82 +334,97 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        # ---- roofline of the dominant kernel from the live per-launch events ---------------
-        agg, layers = {}, {}
-        for full, ms, fl, by, fx in rows:
-            name = full.split("@")[0]
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
-            a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by; a[4] += fx
-            if "@" in full:
-                l = layers.setdefault(full, [0, 0.0, 0.0, 0.0])
-                l[0] += 1; l[1] += ms; l[2] += fl; l[3] += fx
-        roof, kern = None, []
-        if agg:
-            tot_ms = sum(a[1] for a in agg.values())
-            for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                kern.append({"kernel": name, "launches_per_step": a[0] / nprof, "ms_per_frame": round(a[1] / nprof / B, 4),
-                             "tflops": round(a[2] / a[1] / 1e9, 2) if a[1] > 0 else None,
-                             "tflops_executed": round(a[4] / a[1] / 1e9, 2) if a[1] > 0 else None,
-                             "gbs": round(a[3] / a[1] / 1e6, 1) if a[1] > 0 else None})
-            dom = max(agg.items(), key=lambda kv: kv[1][1])
-            achieved = dom[1][2] / dom[1][1] / 1e9
-            mf = [a for n, a in agg.items() if n.startswith(("conv_mfma", "conv_wino", "conv_upw"))]
-            roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(dom[0]),
-                    "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same "
-                                      "command; bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024)",
-                    "algorithmic_bytes_per_launch": round(dom[1][3] / dom[1][0]),
-                    "note": "achieved = ALGORITHMIC FLOPs of the reference's direct 3x3 convolution / event time; the Winograd "
-                            "F(2x2,3x3) kernels execute 2.25x and the upsample-fused ones 4x fewer multiplies, so frac may exceed 1",
-                    "executed_tflops": round(dom[1][4] / dom[1][1] / 1e9, 2),
-                    "executed_frac_of_mfma_peak": round(dom[1][4] / dom[1][1] / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
-                    "avg_launch_ms": round(dom[1][1] / dom[1][0], 5), "share_of_gpu_time": round(dom[1][1] / tot_ms, 3),
-                    "all_matrix_kernels_algorithmic_tflops": round(sum(a[2] for a in mf) / sum(a[1] for a in mf) / 1e9, 2),
-                    "all_matrix_kernels_executed_tflops": round(sum(a[4] for a in mf) / sum(a[1] for a in mf) / 1e9, 2)}
-        # ---- CPU baseline: the numpy oracle (port) on a bounded sample ----------------------
+        roof, kern, layers = roofline_and_kernels(rows, nprof, B, S)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import rerevst_oracle as O
-            o = O.Stylization(weights)
-            o.set_state(model.get_state())
-            nsamp = {256: 6, 512: 3, 1024: 1}.get(S, 2)
-            o.transfer(host[0])                       # warm-up
-            tc = time.perf_counter()
-            for k in range(nsamp):
-                o.transfer(host[(k + 1) % len(host)])
-            tc = time.perf_counter() - tc
-            try:
-                from threadpoolctl import threadpool_info
-                thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-            except Exception:
-                thr = os.cpu_count()
-            cpu = {"value": round(nsamp / tc, 4), "unit": "frames/s", "cores": int(thr), "kind": "port",
-                   "sample": "%d padded %dx%d frames through oracle/rerevst_oracle.py (numpy fp32, BLAS threads=%d of %d host cores)"
-                             % (nsamp, P, P, thr, os.cpu_count())}
-        out = {"metric": "stylized frames/sec at %dx%d, 1 style" % (S, S), "value": round(world * args.steps * B / dt, 3),
+            blobs = [model.get_state(k) for k in range(max(1, NS))]
+            def frame_of(k):
+                return video.reflect_pad(pkg.synth_frame(k, S, S, kind="noise"), P, P)
+            if NS:
+                def setup(O):
+                    o = O.MultiStylization(weights, NS)
+                    for k in range(NS):
+                        o.per_style[k].set_state(blobs[k])
+                    # the encoder pass is the caching step (outside the metric): it runs in make_input, the clock sees the decoder
+                    return (lambda k: o.generate_content_features(frame_of(k))), (lambda f: o.transfer(f, video.ramp_weights(7, NF, NS)))
+                cpu = cpu_baseline(setup, "frames/s", "cached relu4_1 features of padded %dx%d frames, %d-style blended decoder" % (P, P, NS))
+            else:
+                def setup(O):
+                    o = O.Stylization(weights)
+                    o.set_state(blobs[0])
+                    return frame_of, o.transfer
+                cpu = cpu_baseline(setup, "frames/s", "padded %dx%d frames" % (P, P))
+        what = ("%d-frame synthetic %dx%d video (padded %dx%d), %d-style interpolation (decoder only per frame, encoder features "
+                "cached in HBM), frames sharded per GPU" % (NF, S, S, P, P, NS)) if NS else \
+               ("%d-frame synthetic %dx%d video (padded %dx%d), 1 style, frames sharded per GPU" % (NF, S, S, P, P))
+        out = {"metric": "stylized frames/sec at %dx%d, %s" % (S, S, ("%d-style interpolation" % NS) if NS else "1 style"),
+               "value": round(world * args.steps * B / dt, 3),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%d-frame synthetic %dx%d video (padded %dx%d), 1 style, frames sharded per GPU"
-                                      % (NF, S, S, P, P), "frames_per_step_per_gpu": B, "batches_in_flight": args.pipeline, "sampled_frames": len(video.sample_indices(NF)),
+               "config": {"workload": what, "entry": ("rrv_transfer_features: relu4_1 feature in HBM -> float32 frame in %s host memory" if NS else
+                                                      "rrv_transfer_batch: uint8 frames in %s host memory -> float32 frames in the same (H2D + kernels + D2H)")
+                                               % ("pageable" if args.pageable else "page-locked"),
+                          "frames_per_step_per_gpu": B, "sub_batch": 1 if NS else 8, "batches_in_flight": args.pipeline,
+                          "sampled_frames": len(video.sample_indices_multistyle(NF, 16) if NS else video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
-               "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu, "prep_seconds_rank0": round(prep_s, 3), "kernels": kern}
-        if world == 1:
-            # extra, NOT `value`: the driver-level entry on the same frames — unpadded frames in HBM in, cropped frames in
-            # HBM out (rrv_transfer_frames_device: reflect padding and crop inside the first / last kernel, and the
-            # full-resolution layers compute only the tiles the crop window needs).  Same delivered pixels, less work.
-            raw = torch.from_numpy(np.stack([pkg.synth_frame(i, S, S, kind="noise") for i in my_ids[:2 * B]])).to(dev).view(2, B, S, S, 3)
-            d_crop = torch.empty((4, B, S, S, 3), dtype=torch.float32, device=dev)
-            nrep = max(4, min(20, args.steps))
+               "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu,
+               "prep_seconds_rank0": round(prep_s, 3), "kernels": kern}
+        if NS:
+            out["feature_cache_frames_per_s"] = round(len(feats) / cache_s, 1)
+        if world == 1 and not args.no_extras and not NS:
+            # extras, NOT `value`.  (1) HBM -> HBM on the same frames, 8 per launch, two batches in flight (round 1's headline)
+            d_in = torch.from_numpy(np.ascontiguousarray(h_in[0][:16 if B >= 16 else B])).to(dev)
+            nb8 = max(1, d_in.shape[0] // 8)
+            bb = d_in.shape[0] // nb8
+            d_in = d_in[:nb8 * bb].view(nb8, bb, P, P, 3)
+            d_out = torch.empty((4, bb, P, P, 3), dtype=torch.float32, device=dev)
+            nrep = max(8, min(60, args.steps * B // bb))
+            torch.cuda.synchronize()
             for i in range(2):
-                model.transfer_frames_device(raw[i % 2].data_ptr(), B, S, S, d_crop[i & 3].data_ptr())
-            model.sync(); torch.cuda.synchronize()
+                model.transfer_batch_device(d_in[i % nb8].data_ptr(), bb, P, P, d_out[i & 3].data_ptr())
+            model.sync()
             t1 = time.perf_counter()
             for i in range(nrep):
-                model.transfer_frames_device(raw[i % 2].data_ptr(), B, S, S, d_crop[i & 3].data_ptr())
-            model.sync(); torch.cuda.synchronize()
-            out["cropped_entry_frames_per_s"] = round(nrep * B / (time.perf_counter() - t1), 1)
+                model.transfer_batch_device(d_in[i % nb8].data_ptr(), bb, P, P, d_out[i & 3].data_ptr())
+            model.sync()
+            out["device_resident_frames_per_s"] = round(nrep * bb / (time.perf_counter() - t1), 1)
+            # (2) the driver-level entry: UNPADDED frames in, cropped frames out (pad / crop inside the first / last kernel,
+            # full-resolution layers compute only the tiles the crop window needs): device-resident and host -> host
+            raw = torch.from_numpy(np.stack([pkg.synth_frame(i, S, S, kind="noise") for i in my_ids[:2 * bb]])).to(dev).view(2, bb, S, S, 3)
+            d_crop = torch.empty((4, bb, S, S, 3), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            for i in range(2):
+                model.transfer_frames_device(raw[i % 2].data_ptr(), bb, S, S, d_crop[i & 3].data_ptr())
+            model.sync()
+            t1 = time.perf_counter()
+            for i in range(nrep):
+                model.transfer_frames_device(raw[i % 2].data_ptr(), bb, S, S, d_crop[i & 3].data_ptr())
+            model.sync()
+            out["cropped_entry_device_frames_per_s"] = round(nrep * bb / (time.perf_counter() - t1), 1)
+            h_raw = pkg.pinned_empty((B, S, S, 3), np.uint8)
+            for k in range(B):
+                h_raw[k] = pkg.synth_frame(my_ids[k % len(my_ids)], S, S, kind="noise")
+            h_crop = pkg.pinned_empty((B, S, S, 3), np.float32)
+            model.transfer_frames(h_raw, out=h_crop)
+            nr2 = max(2, min(6, args.steps))
+            t1 = time.perf_counter()
+            for i in range(nr2):
+                model.transfer_frames(h_raw, out=h_crop)
+            out["cropped_entry_host_frames_per_s"] = round(nr2 * B / (time.perf_counter() - t1), 1)
+            # (3) the other kind of caller memory, and the reference's one-frame-per-call surface
+            other = (lambda shp, dt: np.empty(shp, dt)) if not args.pageable else pkg.pinned_empty
+            o_in = other((B, P, P, 3), np.uint8); o_in[...] = h_in[0]
+            o_out = other((B, P, P, 3), np.float32)
+            model.transfer_batch(o_in, out=o_out)
+            t1 = time.perf_counter()
+            for i in range(nr2):
+                model.transfer_batch(o_in, out=o_out)
+            out["%s_host_frames_per_s" % ("page_locked" if args.pageable else "pageable")] = round(nr2 * B / (time.perf_counter() - t1), 1)
+            t1 = time.perf_counter()
+            for k in range(min(B, 32)):
+                model.transfer(h_in[0][k])
+            out["one_frame_per_call_frames_per_s"] = round(min(B, 32) / (time.perf_counter() - t1), 1)
         if os.environ.get("RRV_BENCH_LAYERS"):
             out["layers"] = [{"layer": k, "ms_per_frame": round(v[1] / nprof / B, 4), "tflops": round(v[2] / v[1] / 1e9, 1),
                               "tflops_executed": round(v[3] / v[1] / 1e9, 1)}
@@ -242,6 +432,7 @@ def main():
         print(json.dumps(out), flush=True)
     model.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -14,6 +14,7 @@
 #ifndef REREVST_HIP_H
 #define REREVST_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -75,12 +76,20 @@ int rrv_get_state(rrv_handle h, float* out, int n, int style_id);
 int rrv_set_state(rrv_handle h, const float* in, int n, int style_id);
 
 /* Stylization.transfer (test/framework.py:106-118): uint8 BGR HWC [H][W][3] in host
- * memory -> float32 BGR HWC [H][W][3] in 0..255 in host memory.  H and W must be
- * multiples of 8 (the reference driver pads to multiples of 64). */
+ * memory -> float32 BGR HWC [H][W][3] in 0..255 in host memory (includes the H2D / D2H crossings of
+ * framework.py:109 `.to(device)` and :40 `.cpu()`).  H and W must be multiples of 8 (the reference accepts any size
+ * and its output floors to a multiple of 8; its driver pads to multiples of 64) and (H+2)*(W+2)*64 < 2^31
+ * (about 33 Mpixel per frame; RRV_E_ARG beyond).  Page-locked caller buffers (rrv_host_alloc / rrv_host_register)
+ * are DMA'd directly; pageable ones are staged through the library's own pinned buffers. */
 int rrv_transfer(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* out_bgr);
 
 /* Same computation on device-resident buffers (HBM in, HBM out), asynchronous on the
- * handle's stream; rrv_sync() waits.  This is the entry the throughput bench times. */
+ * handle's own (non-blocking) streams; rrv_sync() waits.
+ * ORDERING: the library's streams are NOT ordered against any stream of the caller.  Either (a) make sure the input
+ * is complete before the call (e.g. torch.cuda.synchronize()) and call rrv_sync() before reading the output, or
+ * (b) register the producing / consuming stream once with rrv_set_caller_stream(): every *_device entry then waits
+ * for the work queued on that stream so far and makes that stream wait for its own output (event based, no host
+ * sync), i.e. the call behaves as if it had been enqueued on the caller's stream. */
 int rrv_transfer_device(rrv_handle h, const void* d_frame_bgr_u8, int H, int W, void* d_out_bgr_f32);
 
 /* B frames per launch ([B][H][W][3] in, [B][H][W][3] out, both in HBM): frames are independent
@@ -133,6 +142,18 @@ int rrv_sync(rrv_handle h);
  * tails overlap the other's kernels.  Callers must give consecutive calls distinct output buffers
  * and call rrv_sync() before reading them.  Host-buffer entries and blend transfers are serialised. */
 int rrv_set_pipeline(rrv_handle h, int n_slots);
+
+/* Stream-ordered use of the *_device entries from a caller that produces / consumes the buffers on its own HIP
+ * stream (e.g. torch.cuda.current_stream().cuda_stream): see ORDERING above.  enable = 0 switches it off. */
+int rrv_set_caller_stream(rrv_handle h, void* hip_stream, int enable);
+
+/* Page-locked host memory for the host-buffer entries (no staging copy, true async DMA): allocate, or pin an
+ * existing range in place.  Plain wrappers of hipHostMalloc / hipHostFree / hipHostRegister / hipHostUnregister so
+ * that a caller without HIP bindings (ctypes, cgo, JNI) can use them. */
+int rrv_host_alloc(size_t bytes, void** out);
+int rrv_host_free(void* p);
+int rrv_host_register(void* p, size_t bytes);
+int rrv_host_unregister(void* p);
 
 /* Per-launch timing with HIP events recorded on the handle's own stream.
  * rrv_profile_begin() clears the log and starts bracketing every kernel launch with

@@ -42,10 +42,33 @@ assert STATE_FLOATS == 17536
 
 # ---- primitive operators ---------------------------------------------------------------
 
+# "numpy": nine shifted GEMMs (the default; what the parity tests use).  "torch": the same convolution through
+# torch.nn.functional.conv2d on the CPU — the primitive the reference itself calls (nn.Conv2d -> oneDNN) — used by
+# bench.py's cpu_baseline leg so that the CPU column is timed on the reference's own arithmetic library.
+CONV_BACKEND = "numpy"
+
+
+def set_conv_backend(name):
+    global CONV_BACKEND
+    assert name in ("numpy", "torch")
+    CONV_BACKEND = name
+
+
+def _conv3x3_torch(x, w, b):
+    import torch
+    import torch.nn.functional as TF
+    with torch.no_grad():
+        t = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+        y = TF.conv2d(t, torch.from_numpy(np.ascontiguousarray(w)), None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=F32)), padding=1)
+        return np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy())
+
+
 def conv3x3(x, w, b=None):
     """Zero-pad-1, stride-1 3x3 convolution.  x [B,H,W,Cin] f32, w OIHW [Cout,Cin,3,3].
     (nn.Conv2d(kernel_size=3, padding=1): style_network_global.py:103-104,145,182,186,341;
     vgg19.features convs.)  Evaluated as nine shifted [B*H*W,Cin]x[Cin,Cout] products."""
+    if CONV_BACKEND == "torch":
+        return _conv3x3_torch(x, w, b)
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     xp = np.zeros((B, H + 2, W + 2, Cin), dtype=F32)

@@ -10,7 +10,7 @@ from .synth import synth_frame, synth_style  # noqa: F401
 
 
 def __getattr__(name):
-    if name in ("Stylization", "RRVError", "MultiStyleStylization", "ContentFeature"):
+    if name in ("Stylization", "RRVError", "MultiStyleStylization", "ContentFeature", "pinned_empty"):
         from . import framework
         return getattr(framework, name)
     raise AttributeError(name)

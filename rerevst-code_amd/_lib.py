@@ -43,6 +43,11 @@ SYMBOLS = {
     "rrv_get_preclamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_sync": (C.c_int, [C.c_void_p]),
     "rrv_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+    "rrv_set_caller_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rrv_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rrv_host_free": (C.c_int, [C.c_void_p]),
+    "rrv_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rrv_host_unregister": (C.c_int, [C.c_void_p]),
     "rrv_profile_begin": (C.c_int, [C.c_void_p]),
     "rrv_profile_end": (C.c_int, [C.c_void_p]),
     "rrv_profile_count": (C.c_int, [C.c_void_p]),

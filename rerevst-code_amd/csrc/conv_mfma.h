@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
         const int qq = e & 3;
         if (pp >= NPIX) pp = 0;
         const int hy = pp / HWD, hx = pp - hy * HWD;
-        asrc[it] = ((ys + hy + 1) * (p.Wi + 2) + (xs + hx + 1)) * p.Cin + 4 * (qq ^ ((pp >> 2) & 3));
+        asrc[it] = (hy * (p.Wi + 2) + hx) * p.Cin + 4 * (qq ^ ((pp >> 2) & 3));   // relative to the tile's first halo pixel
     }
+    // 64-bit tile origin (ring coordinates of the first halo pixel), 32-bit tile-relative lane offsets
+    const float* in_t = in_b + ((size_t)(ys + 1) * (p.Wi + 2) + (xs + 1)) * p.Cin;
     const float* wsrc = p.wpk + (size_t)n_tile * nchunks * TAPS * (BN * 16) + tid * 4;
 
     const float* w_tile = p.wpk + (size_t)n_tile * nchunks * TAPS * (BN * 16);
@@ -170,11 +172,11 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
         }
         if (tap == 0) {
             char* adst = smem + (chunk & 1) * A_BYTES;
-            const float* ab = in_b + chunk * 16;
+            const float* ab = in_t + chunk * 16;
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) {
                 if (LD == 1)
-                    bufld16(in_b, adst + (it * 256 + wave * 64) * 16, asrc[it] * 4, chunk * 64);
+                    bufld16(in_t, adst + (it * 256 + wave * 64) * 16, asrc[it] * 4, chunk * 64);
                 else
                     glds16(ab + asrc[it], adst + (it * 256 + wave * 64) * 16);
             }

@@ -177,14 +177,15 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
     bx /= p.tiles_x;
     const int ty = bx % p.tiles_y, b = bx / p.tiles_y;
     const int y0 = (ty + p.ty0) * 16, x0 = (tx + p.tx0) * 16;
-    const float* in_b = p.in + (size_t)b * (size_t)(p.H + 2) * (p.W + 2) * 64;
+    // 64-bit tile origin, tile-relative 32-bit lane offsets: no limit on the frame size from the descriptor's range
+    const float* in_t = p.in + ((size_t)b * (size_t)(p.H + 2) + y0) * (size_t)(p.W + 2) * 64 + (size_t)x0 * 64;
 
     auto stage = [&](int chunk, int buf) {
         for (int e = tid; e < 18 * 18 * 4; e += 256) {
             const int pp = e >> 2, qq = e & 3;
             const int hy = pp / 18, hx = pp - hy * 18;
-            const int off = (((y0 + hy) * (p.W + 2) + x0 + hx) * 64 + 4 * (qq ^ ((pp >> 2) & 3))) * 4;
-            bufld16(in_b, (char*)&s_in[buf][0] + (e - (tid & 63)) * 16, off, chunk * 64);
+            const int off = ((hy * (p.W + 2) + hx) * 64 + 4 * (qq ^ ((pp >> 2) & 3))) * 4;
+            bufld16(in_t, (char*)&s_in[buf][0] + (e - (tid & 63)) * 16, off, chunk * 64);
         }
     };
     stage(0, 0);

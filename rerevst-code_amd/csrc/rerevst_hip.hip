@@ -91,6 +91,9 @@ struct rrv_ctx {
     hipStream_t stream = nullptr;              // stream the launch helpers use (= streams[slot in use])
     hipStream_t streams[RRV_MAX_SLOTS] = {nullptr};
     int n_slots = 2, next_slot = 0, last_slot = 0;   // transfer calls alternate over n_slots (stream, workspace) pairs
+    hipEvent_t slot_ev[RRV_MAX_SLOTS] = {nullptr};   // ordering against the caller's stream (rrv_set_caller_stream)
+    hipStream_t caller_stream = nullptr; bool caller_sync = false;
+    int user_style = -1;                             // style the plain transfer entries use (first computed / last set_state)
     std::string err;
     std::map<std::string, std::vector<float>> hostw;
     std::map<std::string, std::vector<int64_t>> hostshape;
@@ -200,8 +203,9 @@ void conv_launch(const ConvP& p, dim3 grid, hipStream_t s) {
 }
 
 typedef void (*ConvFn)(const ConvP&, dim3, hipStream_t);
-struct ConvKey { int BN, TAPS, UPS, EPI; ConvFn fn; const char* name; };
-#define CK(BN, TAPS, UPS, EPI) {BN, TAPS, UPS, EPI, &conv_launch<BN, TAPS, EPI>, "conv_mfma<" #BN "," #TAPS "," #EPI ">"}
+typedef hipError_t (*AttrFn)();       // per-DEVICE opt-in for > 64 KB of dynamic LDS (run by rrv_create after hipSetDevice)
+struct ConvKey { int BN, TAPS, UPS, EPI; ConvFn fn; const char* name; AttrFn attr; };
+#define CK(BN, TAPS, UPS, EPI) {BN, TAPS, UPS, EPI, &conv_launch<BN, TAPS, EPI>, "conv_mfma<" #BN "," #TAPS "," #EPI ">", nullptr}
 const ConvKey CONV_TABLE[] = {
     // 1x1 shortcuts of the residual blocks (evaluated before the upsample)
     CK(128, 1, 0, 0), CK(64, 1, 0, 0),
@@ -214,25 +218,23 @@ constexpr int UPW_NW = 4;      // upsample-fused form: 4 waves, 54 KB of LDS, tw
 template <int EPI, int NW, int UPS, int SC>
 void wino_launch(const ConvP& p, dim3 grid, hipStream_t s) {
     using Geo = WinoGeo<NW, UPS, SC>;
-    static bool attr_set = false;     // >64 KB of dynamic LDS needs the opt-in attribute once per kernel
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM);
-        attr_set = true;
-    }
     hipLaunchKernelGGL((conv_wino_k<EPI, 0, NW, UPS, SC>), grid, dim3(NW * 64), Geo::SMEM, s, p);
+}
+template <int EPI, int NW, int UPS, int SC>
+hipError_t wino_attr() {
+    return hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<NW, UPS, SC>::SMEM);
 }
 template <int EPI>
 void wsplit_launch(const ConvP& p, dim3 grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wino_split_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES);
-        attr_set = true;
-    }
     hipLaunchKernelGGL((conv_wino_split_k<EPI>), grid, dim3(512), WSPLIT_SMEM_BYTES, s, p);
 }
-#define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI>, "conv_wino<" #EPI ">"}
-#define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 0>, "conv_upw<" #EPI ">"}
-#define UWS(EPI) {32, 10, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 1>, "conv_upw_sc<" #EPI ">"}
+template <int EPI>
+hipError_t wsplit_attr() {
+    return hipFuncSetAttribute((const void*)conv_wino_split_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES);
+}
+#define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI>, "conv_wino<" #EPI ">", &wsplit_attr<EPI>}
+#define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 0>, "conv_upw<" #EPI ">", &wino_attr<EPI, UPW_NW, 1, 0>}
+#define UWS(EPI) {32, 10, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 1>, "conv_upw_sc<" #EPI ">", &wino_attr<EPI, UPW_NW, 1, 1>}
 const ConvKey WINO_TABLE[] = {
     WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
     // KernelFilter 32->512 convs with the folded dynamic filter (+ residual, + AdaIN after Filter3)
@@ -447,12 +449,28 @@ int activate_state(rrv_handle h, int style_id) {
     for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->active_src = style_id;
+    h->user_style = style_id;
     return RRV_OK;
+}
+
+// Plain (non-blend) transfer entries: after a blend (-2) or an invalidation (-1) go back to the style that was
+// active before it — the last one activated by compute() / set_state() — else the first computed one.
+int ensure_active(rrv_handle h) {
+    if (h->active_src >= 0) return RRV_OK;
+    int sid = -1;
+    if (h->user_style >= 0 && h->styles[h->user_style].computed) sid = h->user_style;
+    else
+        for (int s = 0; s < RRV_MAX_STYLES && sid < 0; ++s)
+            if (h->styles[s].computed) sid = s;
+    h->active_src = -1;
+    if (sid < 0) return RRV_OK;        // transfer_device reports "state not computed"
+    return activate_state(h, sid);
 }
 
 // ---- encoder ----------------------------------------------------------------------------
 int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {
     if (e.B == B && e.H == H && e.W == W && e.c11.p) return RRV_OK;
+    if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "image too large ((H+2)*(W+2)*64 must be < 2^31)");
     e.B = B; e.H = H; e.W = W;
     const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
     RCHK(talloc(h, &e.c11, B, H, W, 64));
@@ -475,6 +493,7 @@ struct PadCrop { int src_H, src_W, top, left; };
 // nb > 0: encode only the first nb images of a plan made for more
 int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0, const PadCrop* pc = nullptr, int nb = 0) {
     const int H = e.H, W = e.W, B = (nb > 0 && nb < e.B) ? nb : e.B;
+    if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "image too large ((H+2)*(W+2)*64 must be < 2^31)");
     FirstP fp{d_img, H, W, B, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16,
               which == 0 ? h->first_wg : nullptr, pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
     RCHK(launch(h, "conv_first", 2.0 * B * H * W * 27 * 64, (3.0 + 256.0) * B * H * W, [&] {
@@ -566,6 +585,8 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
     if (h->active_src == -1) return fail(h, RRV_E_STATE, "state not computed: call compute() (or set_state) before transfer()");
     if (B < 1 || B > 64) return fail(h, RRV_E_ARG, "transfer: batch must be in 1..64");
+    // element indices inside one image are 32-bit in the kernels' epilogues: (H+2)(W+2) x 64 channels must stay below 2^31
+    if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
     // consecutive calls alternate over two (stream, workspace) pairs so that the tail / store burst of
     // one batch's kernels overlaps the next batch's kernels (frames are independent)
     const int slot = (h->n_slots > 1 && !h->profiling) ? h->next_slot : 0;
@@ -573,6 +594,10 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     h->last_slot = slot;
     struct StreamScope { rrv_handle h; ~StreamScope() { h->stream = h->streams[0]; } } scope{h};
     h->stream = h->streams[slot];
+    if (h->caller_sync) {    // stream-ordered against the caller: work queued on its stream so far precedes ours
+        HIPCHK(hipEventRecord(h->slot_ev[slot], h->caller_stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->slot_ev[slot], 0));
+    }
     RCHK(enc_plan(h, h->enc_frame[slot], B, H, W));
     RCHK(dec_plan(h, h->dec[slot], B, H, W));
     DecPlan& d = h->dec[slot];
@@ -615,6 +640,10 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     }
     RCHK(resblock_frame(h, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr));
     RCHK(run_last(h, d.o2, B, H, W, d_out, d.pre, pc, roi ? &wl : nullptr));
+    if (h->caller_sync) {    // ... and whatever the caller queues next sees our output
+        HIPCHK(hipEventRecord(h->slot_ev[slot], h->stream));
+        HIPCHK(hipStreamWaitEvent(h->caller_stream, h->slot_ev[slot], 0));
+    }
     return RRV_OK;
 }
 
@@ -753,6 +782,14 @@ int rrv_create(int device, rrv_handle* out) {
         return RRV_E_HIP;
     }
     h->stream = h->streams[0];
+    for (int i = 0; ok && i < RRV_MAX_SLOTS; ++i) ok = hipEventCreateWithFlags(&h->slot_ev[i], hipEventDisableTiming) == hipSuccess;
+    // the dynamic-LDS opt-in is a per-device function attribute: set it for THIS device, whatever other handles did
+    for (const ConvKey& e : WINO_TABLE)
+        if (ok && e.attr) ok = e.attr() == hipSuccess;
+    if (!ok) {
+        delete h;
+        return RRV_E_HIP;
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
@@ -795,7 +832,7 @@ int rrv_destroy(rrv_handle h) {
         if (st.done) (void)hipEventDestroy(st.done);
     }
     for (ProfEntry& e : h->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
-    for (int i = 0; i < RRV_MAX_SLOTS; ++i) (void)hipStreamDestroy(h->streams[i]);
+    for (int i = 0; i < RRV_MAX_SLOTS; ++i) { (void)hipStreamDestroy(h->streams[i]); if (h->slot_ev[i]) (void)hipEventDestroy(h->slot_ev[i]); }
     delete h;
     return RRV_OK;
 }
@@ -923,6 +960,7 @@ int rrv_clean(rrv_handle h) {
     h->patch_h = h->patch_w = h->add_H = h->add_W = 0;
     for (StyleState& s : h->styles) s.computed = false;
     h->active_src = -1;
+    h->user_style = -1;
     return RRV_OK;
 }
 
@@ -1022,11 +1060,7 @@ int rrv_set_state(rrv_handle h, const float* in, int n, int sid) {
 int rrv_transfer_batch_device(rrv_handle h, const void* d_in, int B, int H, int W, void* d_out) {
     if (!h || !d_in || !d_out) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
-    if (h->active_src == -2) h->active_src = -1;
-    if (h->active_src == -1) {
-        for (int s = 0; s < RRV_MAX_STYLES; ++s)
-            if (h->styles[s].computed) { RCHK(activate_state(h, s)); break; }
-    }
+    RCHK(ensure_active(h));
     return transfer_device(h, (const uint8_t*)d_in, B, H, W, (float*)d_out);
 }
 
@@ -1037,11 +1071,7 @@ static int padded_size(int n) { return (n + 128 + 63) / 64 * 64; }      // Resha
 int rrv_transfer_frames_device(rrv_handle h, const void* d_in, int B, int H, int W, void* d_out) {
     if (!h || !d_in || !d_out || H < 1 || W < 1) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
-    if (h->active_src == -2) h->active_src = -1;
-    if (h->active_src == -1) {
-        for (int s = 0; s < RRV_MAX_STYLES; ++s)
-            if (h->styles[s].computed) { RCHK(activate_state(h, s)); break; }
-    }
+    RCHK(ensure_active(h));
     const PadCrop pc{H, W, 64, 64};
     return transfer_device(h, (const uint8_t*)d_in, B, padded_size(H), padded_size(W), (float*)d_out, nullptr, &pc);
 }
@@ -1112,11 +1142,26 @@ static void host_copy(void* dst, const void* src, size_t bytes) {
     memcpy(dst, src, slice < bytes ? slice : bytes);
     for (int t = 1; t < nt; ++t) th[t - 1].join();
 }
+// caller buffers that are page-locked (rrv_host_alloc / rrv_host_register, or any hipHostMalloc'ed / registered range)
+// are DMA'd directly: no staging copy through the library's pinned buffers
+static bool is_pinned(const void* ptr, size_t bytes) {
+    hipPointerAttribute_t a;
+    for (const char* q : {(const char*)ptr, (const char*)ptr + (bytes ? bytes - 1 : 0)}) {
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
 static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out, bool pad_on_device = false) {
     if (!h || !frames || !out || B < 1) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     const size_t fb = (size_t)H * W * 3;
     const int sub = B < HOST_SUB ? B : HOST_SUB;
+    {   // refuse oversized frames before any staging buffer is sized for them
+        const double ph = pad_on_device ? (double)((H + 128 + 63) / 64 * 64) : (double)H, pw = pad_on_device ? (double)((W + 128 + 63) / 64 * 64) : (double)W;
+        if (H < 1 || W < 1 || (ph + 2) * (pw + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
+    }
+    const bool in_pin = is_pinned(frames, (size_t)B * fb), out_pin = is_pinned(out, (size_t)B * fb * sizeof(float));
     RCHK(sync_all(h));
     for (auto& st : h->hstage) {
         if (st.cap >= (size_t)sub * fb) continue;
@@ -1134,25 +1179,26 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
     }
     const int nchunk = (B + sub - 1) / sub;
     auto count = [&](int k) { return (k + 1) * sub <= B ? sub : B - k * sub; };
-    auto drain = [&](int k) -> int {       // sub-batch k back to the caller
+    auto drain = [&](int k) -> int {       // sub-batch k back to the caller (or, for a page-locked output, just its completion)
         auto& st = h->hstage[k & 1];
         HIPCHK(hipEventSynchronize(st.done));
-        host_copy(out + (size_t)k * sub * fb, st.pin_out, (size_t)count(k) * fb * sizeof(float));
+        if (!out_pin) host_copy(out + (size_t)k * sub * fb, st.pin_out, (size_t)count(k) * fb * sizeof(float));
         return RRV_OK;
     };
     int rc = RRV_OK;
     for (int k = 0; k < nchunk && rc == RRV_OK; ++k) {
         auto& st = h->hstage[k & 1];
-        if (k >= 2) rc = drain(k - 2);
+        if (k >= 2) rc = drain(k - 2);     // also frees the staging set for re-use
         if (rc != RRV_OK) break;
         const int nb = count(k);
-        host_copy(st.pin_in, frames + (size_t)k * sub * fb, (size_t)nb * fb);
+        const uint8_t* src = frames + (size_t)k * sub * fb;
+        if (!in_pin) { host_copy(st.pin_in, src, (size_t)nb * fb); src = st.pin_in; }
         h->next_slot = (k & 1) % h->n_slots;
         hipStream_t sm = h->streams[h->profiling ? 0 : h->next_slot];
-        HIPCHK(hipMemcpyAsync(st.d_in, st.pin_in, (size_t)nb * fb, hipMemcpyHostToDevice, sm));
+        HIPCHK(hipMemcpyAsync(st.d_in, src, (size_t)nb * fb, hipMemcpyHostToDevice, sm));
         rc = pad_on_device ? rrv_transfer_frames_device(h, st.d_in, nb, H, W, st.d_out) : rrv_transfer_batch_device(h, st.d_in, nb, H, W, st.d_out);
         if (rc != RRV_OK) break;
-        HIPCHK(hipMemcpyAsync(st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, sm));
+        HIPCHK(hipMemcpyAsync(out_pin ? (void*)(out + (size_t)k * sub * fb) : (void*)st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, sm));
         HIPCHK(hipEventRecord(st.done, sm));
     }
     if (rc != RRV_OK) { (void)sync_all(h); h->next_slot = 0; return rc; }
@@ -1317,6 +1363,27 @@ int rrv_set_pipeline(rrv_handle h, int n_slots) {
     RCHK(sync_all(h));
     h->n_slots = n_slots;
     h->next_slot = 0;
+    return RRV_OK;
+}
+
+int rrv_host_alloc(size_t bytes, void** out) {
+    if (!out || !bytes) return RRV_E_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? RRV_OK : RRV_E_NOMEM;
+}
+int rrv_host_free(void* p) { return (p && hipHostFree(p) == hipSuccess) ? RRV_OK : RRV_E_ARG; }
+int rrv_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return RRV_E_ARG;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? RRV_OK : RRV_E_HIP;
+}
+int rrv_host_unregister(void* p) { return (p && hipHostUnregister(p) == hipSuccess) ? RRV_OK : RRV_E_ARG; }
+
+int rrv_set_caller_stream(rrv_handle h, void* stream, int enable) {
+    if (!h) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    h->caller_stream = (hipStream_t)stream;
+    h->caller_sync = enable != 0;
     return RRV_OK;
 }
 

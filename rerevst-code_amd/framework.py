@@ -15,6 +15,21 @@ class RRVError(RuntimeError):
     pass
 
 
+def pinned_empty(shape, dtype=np.float32):
+    """A numpy array in page-locked host memory (rrv_host_alloc): the host-buffer entries DMA straight from / into
+    it instead of staging through the library's own pinned buffers.  Freed when the last view of it dies."""
+    import weakref
+    lib = _lib.load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = C.c_void_p()
+    if lib.rrv_host_alloc(max(n, 1), C.byref(ptr)) != 0:
+        raise MemoryError("rrv_host_alloc(%d) failed" % n)
+    buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+    weakref.finalize(buf, lib.rrv_host_free, ptr)
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
 def _u8_image(img, what):
     a = np.ascontiguousarray(img)
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
@@ -166,6 +181,11 @@ class Stylization():
     def sync(self):
         self._chk(self._lib.rrv_sync(self._h))
 
+    def set_caller_stream(self, stream_ptr, enable=True):
+        """Order the *_device entries against the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream):
+        they wait for what is queued on it and it waits for their output — no host synchronisation needed."""
+        self._chk(self._lib.rrv_set_caller_stream(self._h, C.c_void_p(stream_ptr), 1 if enable else 0))
+
     def set_pipeline(self, n_slots):
         """1: every device-entry call runs on one stream; 2 (default): consecutive calls alternate over two
         (stream, workspace) pairs so two independent batches are in flight."""
@@ -231,9 +251,12 @@ class MultiStyleStylization(Stylization):
     def compute_norm(self):
         self.compute()
 
-    def transfer(self, cur_feature, style_weight=[1.]):
+    def transfer(self, cur_feature, style_weight=[1.], out=None):
         H, W = cur_feature.shape[:2]
-        out = np.empty((H, W, 3), dtype=np.float32)
+        if out is None:
+            out = np.empty((H, W, 3), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (H, W, 3) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape %r" % ((H, W, 3),))
         w = (C.c_float * len(style_weight))(*[float(v) for v in style_weight])
         self._chk(self._lib.rrv_transfer_features(self._h, cur_feature.id, w, len(style_weight), out.ctypes.data_as(C.c_void_p)))
         return out

@@ -16,7 +16,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # pre-clamp output of std 0.165):
 PRE_ATOL, PRE_RTOL = 1e-4, 1e-3      # pre-clamp network output (normalised image units)
 IMG_ATOL = 0.05                      # final image, grey levels of 255
-STATE_ATOL, STATE_RTOL = 2e-5, 3e-4  # saved-state blob
+# saved-state blob: SURVEY §8(c)'s rel 1e-4 plus an absolute floor for entries near zero (a per-channel mean is a
+# sum with cancellation: its error is ~1e-6 ABSOLUTE whatever its value, so a purely relative bound is meaningless
+# for means close to 0; measured oracle-vs-reference: mean |d| <= 5e-6, rstd / lo / hi rel <= 5e-5, filters |d| <= 1e-7)
+STATE_ATOL, STATE_RTOL = 2e-5, 1e-4
 
 
 def pytest_configure(config):

@@ -128,11 +128,11 @@ def run_case(name, weights, style_hw, frame_hw, n_frames, sample_ids, transfer_i
     np.savez(os.path.join(HERE, name + ".npz"), **g)
 
 
-def run_multistyle(name, weights):
-    """S=2 multi-style interpolation ("Multi-style Interpolation/"): per-style state blobs and
-    one blended transfer with weights [0.3, 0.7]."""
+def run_multistyle(name, weights, S=2, wts=(0.3, 0.7)):
+    """S-style interpolation ("Multi-style Interpolation/"): per-style state blobs and
+    one blended transfer with weights `wts`."""
     sty_mod, net_mod = R.import_reference("Multi-style Interpolation", "stylization", "style_network")
-    S = 2
+    wts = [float(v) for v in wts]
     s = sty_mod.Stylization.__new__(sty_mod.Stylization)
     s.device = torch.device("cpu")
     s.transformer = net_mod.TransformerNet(style_num=S)
@@ -141,7 +141,7 @@ def run_multistyle(name, weights):
         new[k] = torch.from_numpy(weights[k].copy()) if k in weights else torch.zeros_like(v)
         assert k in weights or k.startswith("Vgg19."), k
     s.transformer.load_state_dict(new, strict=True)
-    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7), pkg.synth_style(64, 64, kind="smooth", seed=8)]
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7 + k) for k in range(S)]
     frames = [pkg.synth_frame(i, 64, 48, kind="smooth") for i in range(3)]
     padded = [O.reflect_pad(f, 192, 192) for f in frames]
     s.prepare_style(styles)
@@ -150,7 +150,6 @@ def run_multistyle(name, weights):
     for i in (0, 2):
         s.add_patch(feats[i])
     s.compute_norm()
-    wts = [0.3, 0.7]
     out = s.transfer(feats[1], wts)
     with torch.no_grad():
         pre = nhwc(s.transformer(feats[1], wts))[0]
@@ -177,10 +176,10 @@ def run_multistyle(name, weights):
         o.add_patch(of[i])
     o.compute_norm()
     opre = o.transfer(of[1], wts, return_preclamp=True)[0]
-    print("[%s] state rel err max %.3e / %.3e | pre-clamp max|d| %.3e (std %.3f) | image max|d| %.4f"
-          % (name, *(float((np.abs(o.get_state(i) - blobs[i]) / (np.abs(blobs[i]) + 1e-3)).max()) for i in range(2)),
+    print("[%s] state rel err max %s | pre-clamp max|d| %.3e (std %.3f) | image max|d| %.4f"
+          % (name, " / ".join("%.3e" % float((np.abs(o.get_state(i) - blobs[i]) / (np.abs(blobs[i]) + 1e-3)).max()) for i in range(S)),
              np.abs(opre - pre).max(), pre.std(), np.abs(o.transfer(of[1], wts) - out).max()))
-    np.savez(os.path.join(HERE, name + ".npz"), state0=blobs[0], state1=blobs[1], weights=np.array(wts, np.float32),
+    np.savez(os.path.join(HERE, name + ".npz"), **{"state%d" % i: blobs[i] for i in range(S)}, weights=np.array(wts, np.float32),
              pre_crop=pre[64:128, 64:112].astype(np.float32), out_crop=out[64:128, 64:112].astype(np.float32))
 
 
@@ -212,6 +211,40 @@ def run_frame_mode(name, weights):
              out_crop=out[64:128, 64:112].astype(np.float32))
 
 
+def run_config2(name, weights):
+    """BASELINE config 2 geometry: 100-frame 256x256 video (padded 384x384), 512x512 style, the driver's sampling
+    schedule (13 sampled frames: two encoder groups in the HIP library's deferred add, B = 13 in compute()).
+    Stored: the state blob, and the pre-clamp / final crops of one non-sampled frame on a stride-4 pixel grid plus
+    per-channel means (the full 256x256x3 float images would be 1.5 MB)."""
+    s, G = load_ref(weights)
+    style = pkg.synth_style(512, 512, kind="smooth", seed=7)
+    n = 100
+    ids = O.sample_indices(n)
+    tid = 50
+    s.prepare_style(style)
+    s.clean()
+    for i in ids:
+        s.add(pkg.synth_frame(i, 256, 256, kind="smooth"))
+    s.compute()
+    blob = ref_state_blob(s.model)
+    frame = pkg.synth_frame(tid, 256, 256, kind="smooth")
+    padded = O.reflect_pad(frame, 384, 384)
+    taps = {}
+    hk = s.model.Decoder.slice1.register_forward_hook(lambda m, i, o: taps.__setitem__("pre", nhwc(o)))
+    out = s.transfer(padded.copy())
+    hk.remove()
+    pre = taps["pre"][0][64:320, 64:320]
+    out = out[64:320, 64:320]
+    o = O.Stylization(weights)
+    o.set_state(blob)
+    opre = o.transfer(padded, return_preclamp=True)[0][64:320, 64:320]
+    print("[%s] B=%d | oracle (reference state) pre-clamp max|d| %.3e (std %.3f) | sat frac %.3f"
+          % (name, len(ids), np.abs(opre - pre).max(), pre.std(), float(np.mean((out <= 0) | (out >= 255)))))
+    np.savez(os.path.join(HERE, name + ".npz"), state=blob, n_frames=np.array(n), sample_ids=np.array(ids), transfer_id=np.array(tid),
+             pre_grid=pre[::4, ::4].astype(np.float32), out_grid=out[::4, ::4].astype(np.float32),
+             pre_chanmean=pre.mean(axis=(0, 1)).astype(np.float32), out_chanmean=out.mean(axis=(0, 1)).astype(np.float32))
+
+
 def main():
     w = pkg.synthetic_weights(0)
     # A: 3 sampled frames (Q1,Q3,Q4), transfer of a NON-sampled frame, full padded output
@@ -219,7 +252,9 @@ def main():
     # B: frame sides not multiples of 8 (pool floors in add), P=256x192, cropped output only
     run_case("global_b", w, (72, 56), (90, 50), 3, [0, 2], 1, crop_only=True)
     run_multistyle("multistyle_s2", w)
+    run_multistyle("multistyle_s4", w, S=4, wts=(0.1, 0.2, 0.3, 0.4))
     run_frame_mode("frame_mode", w)
+    run_config2("config2_256", w)
 
 
 if __name__ == "__main__":

@@ -94,6 +94,41 @@ def test_multistyle_blend_matches_reference(oracle, pkg, weights):
     assert oracle.sample_indices_multistyle(33) == [0, 16, 32, 32]
 
 
+def test_multistyle_s4_blend_matches_reference(oracle, pkg, weights):
+    """BASELINE config 5 has FOUR styles: per-style blobs + one blended transfer with weights (.1,.2,.3,.4)."""
+    g = load_golden("multistyle_s4")
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7 + k) for k in range(4)]
+    frames = [pkg.synth_frame(i, 64, 48, kind="smooth") for i in range(3)]
+    padded = [oracle.reflect_pad(f, 192, 192) for f in frames]
+    o = oracle.MultiStylization(weights, 4)
+    o.prepare_style(styles)
+    feats = [o.generate_content_features(p) for p in padded]
+    o.clean()
+    for i in (0, 2):
+        o.add_patch(feats[i])
+    o.compute_norm()
+    for k in range(4):
+        assert_state_close(o.get_state(k), g["state%d" % k], "style %d" % k)
+    wts = [float(v) for v in g["weights"]]
+    assert_pre_close(o.transfer(feats[1], wts, return_preclamp=True)[0][64:128, 64:112], g["pre_crop"])
+    assert np.abs(o.transfer(feats[1], wts)[64:128, 64:112] - g["out_crop"]).max() <= IMG_ATOL
+
+
+def test_config2_geometry_matches_reference(oracle, pkg, weights):
+    """BASELINE config 2 geometry (256x256 frame padded to 384x384, 512x512 style): the oracle's per-frame path with
+    the REFERENCE's state (B = 13 sampled frames) against the reference's own output."""
+    g = load_golden("config2_256")
+    o = oracle.Stylization(weights)
+    o.set_state(g["state"])
+    padded = oracle.reflect_pad(pkg.synth_frame(int(g["transfer_id"]), 256, 256, kind="smooth"), 384, 384)
+    pre = o.transfer(padded, return_preclamp=True)[0][64:320, 64:320]
+    assert_pre_close(pre[::4, ::4], g["pre_grid"])
+    np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=1e-5)
+    out = oracle.tensor_to_image(o.transfer(padded, return_preclamp=True))[64:320, 64:320]
+    assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
+    assert [int(i) for i in g["sample_ids"]] == oracle.sample_indices(100)
+
+
 def test_frame_mode_matches_reference(oracle, pkg, weights):
     """use_Global=False model (test/style_network_frame.py): per-frame statistics, no saved state."""
     g = load_golden("frame_mode")
