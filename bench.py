@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--multistyle", type=int, default=0, help="S > 0: BASELINE config 5, S-style interpolation, decoder only per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--profile-steps", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=2, help="sub-batches in flight per GPU (1 or 2 HIP streams)")
     ap.add_argument("--pageable", action="store_true", help="time the host entry with pageable caller arrays instead of page-locked ones")
     args = ap.parse_args()

@@ -126,8 +126,10 @@ struct rrv_ctx {
     const float* last_pre = nullptr; int last_pre_H = 0, last_pre_W = 0;   // where rrv_get_preclamp finds the last tap
     // host-buffer entry: two staging sets (pinned host + device, input and output) so that H2D / kernels / D2H /
     // the copies from and to the caller's pageable arrays of consecutive sub-batches overlap
+    // Four sets and two dedicated copy streams: the compute streams never wait behind a DMA of their own stream.
     struct HostStage { uint8_t* pin_in = nullptr; float* pin_out = nullptr; uint8_t* d_in = nullptr; float* d_out = nullptr;
-                       size_t cap = 0; hipEvent_t done = nullptr; } hstage[2];
+                       size_t cap = 0, pcap = 0; hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr; } hstage[4];
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
     int n_cus = 256;
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -152,6 +154,8 @@ int fail(rrv_handle h, int code, const std::string& msg) { h->err = msg; return 
 int sync_all(rrv_handle h) {
     for (int i = 0; i < RRV_MAX_SLOTS; ++i)
         if (h->streams[i]) HIPCHK(hipStreamSynchronize(h->streams[i]));
+    if (h->copy_in) HIPCHK(hipStreamSynchronize(h->copy_in));
+    if (h->copy_out) HIPCHK(hipStreamSynchronize(h->copy_out));
     return RRV_OK;
 }
 
@@ -782,7 +786,10 @@ int rrv_create(int device, rrv_handle* out) {
         return RRV_E_HIP;
     }
     h->stream = h->streams[0];
+    ok = ok && hipStreamCreateWithFlags(&h->copy_in, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->copy_out, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < RRV_MAX_SLOTS; ++i) ok = hipEventCreateWithFlags(&h->slot_ev[i], hipEventDisableTiming) == hipSuccess;
+    for (auto& st : h->hstage)
+        for (hipEvent_t* e : {&st.in_done, &st.k_done, &st.out_done}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     // the dynamic-LDS opt-in is a per-device function attribute: set it for THIS device, whatever other handles did
     for (const ConvKey& e : WINO_TABLE)
         if (ok && e.attr) ok = e.attr() == hipSuccess;
@@ -829,8 +836,10 @@ int rrv_destroy(rrv_handle h) {
         if (st.pin_out) (void)hipHostFree(st.pin_out);
         if (st.d_in) (void)hipFree(st.d_in);
         if (st.d_out) (void)hipFree(st.d_out);
-        if (st.done) (void)hipEventDestroy(st.done);
+        for (hipEvent_t e : {st.in_done, st.k_done, st.out_done}) if (e) (void)hipEventDestroy(e);
     }
+    if (h->copy_in) (void)hipStreamDestroy(h->copy_in);
+    if (h->copy_out) (void)hipStreamDestroy(h->copy_out);
     for (ProfEntry& e : h->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     for (int i = 0; i < RRV_MAX_SLOTS; ++i) { (void)hipStreamDestroy(h->streams[i]); if (h->slot_ev[i]) (void)hipEventDestroy(h->slot_ev[i]); }
     delete h;
@@ -1123,9 +1132,12 @@ static int host_roundtrip(rrv_handle h, const uint8_t* frames, int B, int H, int
     return RRV_OK;
 }
 
-// B frames in sub-batches of up to 8 through the two staging sets: while sub-batch k runs on its stream, k+1 is
-// copied in and k-1 is copied back to the caller's array.
+// B frames in sub-batches of up to 8 through four staging sets.  Three engines run concurrently: the H2D copy of
+// sub-batch k+1.. (copy_in stream), the kernels of k and k+1 (the two compute streams), the D2H copy of k-1 (copy_out
+// stream); events order a set's H2D -> kernels -> D2H and its re-use four sub-batches later.  With pageable caller
+// arrays the host additionally copies into / out of the pinned staging buffers while all of that runs.
 constexpr int HOST_SUB = 8;
+constexpr int HOST_SETS = 4;
 // copies between the caller's pageable arrays and the pinned staging buffers: first-touch page faults of a fresh
 // output array make a single thread slower than the GPU, so large copies are split over a few threads
 static void host_copy(void* dst, const void* src, size_t bytes) {
@@ -1163,46 +1175,65 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
     }
     const bool in_pin = is_pinned(frames, (size_t)B * fb), out_pin = is_pinned(out, (size_t)B * fb * sizeof(float));
     RCHK(sync_all(h));
-    for (auto& st : h->hstage) {
-        if (st.cap >= (size_t)sub * fb) continue;
-        if (st.pin_in) (void)hipHostFree(st.pin_in);
-        if (st.pin_out) (void)hipHostFree(st.pin_out);
-        if (st.d_in) (void)hipFree(st.d_in);
-        if (st.d_out) (void)hipFree(st.d_out);
-        st.pin_in = nullptr; st.pin_out = nullptr; st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
-        HIPCHK(hipHostMalloc((void**)&st.pin_in, (size_t)sub * fb, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void**)&st.pin_out, (size_t)sub * fb * sizeof(float), hipHostMallocDefault));
-        HIPCHK(hipMalloc((void**)&st.d_in, (size_t)sub * fb));
-        HIPCHK(hipMalloc((void**)&st.d_out, (size_t)sub * fb * sizeof(float)));
-        if (!st.done) HIPCHK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
-        st.cap = (size_t)sub * fb;
-    }
     const int nchunk = (B + sub - 1) / sub;
+    const int nsets = nchunk < HOST_SETS ? nchunk : HOST_SETS;
+    for (int i = 0; i < nsets; ++i) {
+        auto& st = h->hstage[i];
+        if (st.cap < (size_t)sub * fb) {
+            if (st.d_in) (void)hipFree(st.d_in);
+            if (st.d_out) (void)hipFree(st.d_out);
+            st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
+            HIPCHK(hipMalloc((void**)&st.d_in, (size_t)sub * fb));
+            HIPCHK(hipMalloc((void**)&st.d_out, (size_t)sub * fb * sizeof(float)));
+            st.cap = (size_t)sub * fb;
+        }
+        if ((!in_pin || !out_pin) && st.pcap < (size_t)sub * fb) {     // pinned staging only for pageable caller arrays
+            if (st.pin_in) (void)hipHostFree(st.pin_in);
+            if (st.pin_out) (void)hipHostFree(st.pin_out);
+            st.pin_in = nullptr; st.pin_out = nullptr; st.pcap = 0;
+            HIPCHK(hipHostMalloc((void**)&st.pin_in, (size_t)sub * fb, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&st.pin_out, (size_t)sub * fb * sizeof(float), hipHostMallocDefault));
+            st.pcap = (size_t)sub * fb;
+        }
+    }
     auto count = [&](int k) { return (k + 1) * sub <= B ? sub : B - k * sub; };
-    auto drain = [&](int k) -> int {       // sub-batch k back to the caller (or, for a page-locked output, just its completion)
-        auto& st = h->hstage[k & 1];
-        HIPCHK(hipEventSynchronize(st.done));
+    auto drain = [&](int k) -> int {       // sub-batch k delivered (its staging set is free again)
+        auto& st = h->hstage[k % HOST_SETS];
+        HIPCHK(hipEventSynchronize(st.out_done));
         if (!out_pin) host_copy(out + (size_t)k * sub * fb, st.pin_out, (size_t)count(k) * fb * sizeof(float));
         return RRV_OK;
     };
     int rc = RRV_OK;
     for (int k = 0; k < nchunk && rc == RRV_OK; ++k) {
-        auto& st = h->hstage[k & 1];
-        if (k >= 2) rc = drain(k - 2);     // also frees the staging set for re-use
+        auto& st = h->hstage[k % HOST_SETS];
+        const bool reuse = k >= HOST_SETS;
+        if (reuse && (!in_pin || !out_pin)) rc = drain(k - HOST_SETS);   // pinned staging of this set is about to be overwritten
         if (rc != RRV_OK) break;
         const int nb = count(k);
         const uint8_t* src = frames + (size_t)k * sub * fb;
         if (!in_pin) { host_copy(st.pin_in, src, (size_t)nb * fb); src = st.pin_in; }
-        h->next_slot = (k & 1) % h->n_slots;
-        hipStream_t sm = h->streams[h->profiling ? 0 : h->next_slot];
-        HIPCHK(hipMemcpyAsync(st.d_in, src, (size_t)nb * fb, hipMemcpyHostToDevice, sm));
+        const int slot = h->profiling ? 0 : (k & 1) % h->n_slots;
+        hipStream_t cs = h->streams[slot];
+        if (reuse) HIPCHK(hipStreamWaitEvent(h->copy_in, st.k_done, 0));       // the kernels of k-4 have read d_in
+        HIPCHK(hipMemcpyAsync(st.d_in, src, (size_t)nb * fb, hipMemcpyHostToDevice, h->copy_in));
+        HIPCHK(hipEventRecord(st.in_done, h->copy_in));
+        HIPCHK(hipStreamWaitEvent(cs, st.in_done, 0));
+        if (reuse) HIPCHK(hipStreamWaitEvent(cs, st.out_done, 0));             // d_out of k-4 has left the device
+        h->next_slot = slot;
         rc = pad_on_device ? rrv_transfer_frames_device(h, st.d_in, nb, H, W, st.d_out) : rrv_transfer_batch_device(h, st.d_in, nb, H, W, st.d_out);
         if (rc != RRV_OK) break;
-        HIPCHK(hipMemcpyAsync(out_pin ? (void*)(out + (size_t)k * sub * fb) : (void*)st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, sm));
-        HIPCHK(hipEventRecord(st.done, sm));
+        HIPCHK(hipEventRecord(st.k_done, cs));
+        HIPCHK(hipStreamWaitEvent(h->copy_out, st.k_done, 0));
+        HIPCHK(hipMemcpyAsync(out_pin ? (void*)(out + (size_t)k * sub * fb) : (void*)st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
+        HIPCHK(hipEventRecord(st.out_done, h->copy_out));
     }
     if (rc != RRV_OK) { (void)sync_all(h); h->next_slot = 0; return rc; }
-    for (int k = nchunk - 2 < 0 ? 0 : nchunk - 2; k < nchunk; ++k) RCHK(drain(k));
+    const int first_open = (!in_pin || !out_pin) ? (nchunk - HOST_SETS < 0 ? 0 : nchunk - HOST_SETS) : 0;
+    if (in_pin && out_pin) {               // nothing to copy on the host: the last D2H of each stream order completes everything
+        HIPCHK(hipStreamSynchronize(h->copy_out));
+    } else {
+        for (int k = first_open; k < nchunk; ++k) RCHK(drain(k));
+    }
     h->next_slot = 0;
     return RRV_OK;
 }
