@@ -62,6 +62,7 @@ struct ConvP {
     int xcd_slabs;     // conv_wino_k: co-locate the cout slabs of a pixel tile on one XCD (see conv_wino.h)
     float* sc_out;     // conv_wino_k<.., UPS = 1, SC = 1>: low-resolution output of the fused 1x1 shortcut [B,Hi,Wi,Cout] (ring layout)
     int ty0, tx0;      // transform-domain kernels: first tile row / column of the output window (tiles_x, tiles_y count its tiles)
+    long long* dbg;    // microbench only (ABL & 16): per-phase cycle counters
 };
 
 template <int BN>
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvP p) {
         __builtin_amdgcn_s_waitcnt(0);   // drain stores so t_end includes them
         const long long t_end = clock64();
         if (lane == 0) {
-            long long* dbg = (long long*)p.n1;   // microbench passes a debug buffer here
+            long long* dbg = p.dbg;   // microbench only
             const int wg = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
             dbg[wg * 4 + 0] = t_start; dbg[wg * 4 + 1] = t_loop; dbg[wg * 4 + 2] = t_issued; dbg[wg * 4 + 3] = t_end;
         }

@@ -126,6 +126,55 @@ __device__ __forceinline__ f32x4 f4add(const f32x4 a, const f32x4 b) {   // (the
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+// ---- epilogue arithmetic on 4-channel vectors.  Written on 2-wide halves the compiler selects v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32 by itself (two elements per instruction, freely scheduled, no inline-asm hazard nops);
+// it has no packed form for a subtraction or for a literal operand, so those go through f4sub / an opaque register;
+// the saved-range clamp is ONE v_med3_f32 (lo <= hi by construction: med3(v, lo, hi) == min(hi, max(lo, v))).
+// Same roundings as the scalar forms: (v - m) * r is still a subtraction followed by a multiplication.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define F4_LO(v) __builtin_shufflevector(v, v, 0, 1)
+#define F4_HI(v) __builtin_shufflevector(v, v, 2, 3)
+__device__ __forceinline__ f32x4 e4add(const f32x4 a, const f32x4 b) {
+    const f32x2_t lo = F4_LO(a) + F4_LO(b), hi = F4_HI(a) + F4_HI(b);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 e4mul(const f32x4 a, const f32x4 b) {
+    const f32x2_t lo = F4_LO(a) * F4_LO(b), hi = F4_HI(a) * F4_HI(b);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 e4fma(const f32x4 a, const f32x4 b, const f32x4 c) {   // a * b + c, fused
+    const f32x2_t lo = __builtin_elementwise_fma(F4_LO(a), F4_LO(b), F4_LO(c)), hi = __builtin_elementwise_fma(F4_HI(a), F4_HI(b), F4_HI(c));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ float med3(float v, float lo, float hi) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));   // (the builtin canonicalises its inputs first: +1 v_max each)
+    return r;
+}
+__device__ __forceinline__ f32x4 f4relu(f32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    return v;
+}
+__device__ __forceinline__ f32x4 f4lrelu(const f32x4 v) {      // LeakyReLU(0.2): v >= 0 ? v : 0.2 v == max(v, 0.2 v)
+    float k = 0.2f;
+    asm volatile("" : "+s"(k));                                 // opaque: a literal would be scalarised into four v_mul_f32
+    const f32x2_t k2 = {k, k};
+    const f32x2_t lo = F4_LO(v) * k2, hi = F4_HI(v) * k2;
+    const f32x4 s = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf(v[e], s[e]);
+    return r;
+}
+__device__ __forceinline__ f32x4 f4norm_clamp(const f32x4 v, const f32x4 m, const f32x4 r, const f32x4 lo, const f32x4 hi) {
+    const f32x4 n = e4mul(f4sub(v, m), r);      // InstanceNorm.forward: (x - mean) * rstd, clamped to the saved range
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = med3(n[e], lo[e], hi[e]);
+    return o;
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -489,27 +538,12 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
                 for (int j = 0; j < 2; ++j) {
                     const int y = yb + i, x = xb + j;
                     const bool valid = (y < p.H) && (x < p.W);
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float tv = Y[i][j][e] + bias[e];
-                        if (EPI & E_RELU) tv = fmaxf(tv, 0.f);
-                        if (EPI & E_LRELU) tv = (tv >= 0.f) ? tv : tv * 0.2f;
-                        if (EPI & E_NORM1) {
-                            tv = (tv - m1[e]) * r1[e];
-                            tv = fminf(hi1[e], fmaxf(lo1[e], tv));
-                        }
-                        o[e] = tv;
-                    }
-                    if (EPI & (E_RES | E_RES_UPS)) o += resv[nb][i][j];
-                    if (EPI & E_NORM2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float tv = (o[e] - m2[e]) * r2[e];
-                            tv = fminf(hi2[e], fmaxf(lo2[e], tv));
-                            o[e] = tv * sstd[e] + smean[e];
-                        }
-                    }
+                    f32x4 o = e4add(Y[i][j], bias);
+                    if (EPI & E_RELU) o = f4relu(o);
+                    if (EPI & E_LRELU) o = f4lrelu(o);
+                    if (EPI & E_NORM1) o = f4norm_clamp(o, m1, r1, lo1, hi1);
+                    if (EPI & (E_RES | E_RES_UPS)) o = e4add(o, resv[nb][i][j]);
+                    if (EPI & E_NORM2) o = e4fma(f4norm_clamp(o, m2, r2, lo2, hi2), sstd, smean);
                     if (EPI & E_POOL) {
                         if (i == 0 && j == 0) pooled = o;
                         else {
@@ -532,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         tick(5);                              // epilogue issue
     }
     if ((ABL & 16) && lane == 0) {
-        long long* dbg = (long long*)p.n1;   // microbench passes a debug buffer here
+        long long* dbg = p.dbg;   // microbench only
 #pragma unroll
         for (int k = 0; k < 6; ++k) dbg[(blockIdx.x * NW + wave) * 6 + k] = tl[k];
     }

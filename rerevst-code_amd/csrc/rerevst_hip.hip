@@ -1214,6 +1214,17 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
         if (!in_pin) { host_copy(st.pin_in, src, (size_t)nb * fb); src = st.pin_in; }
         const int slot = h->profiling ? 0 : (k & 1) % h->n_slots;
         hipStream_t cs = h->streams[slot];
+        if (nchunk == 1) {     // one sub-batch (the reference's one-frame-per-call surface): nothing to overlap, one stream, no events
+            HIPCHK(hipMemcpyAsync(st.d_in, src, (size_t)nb * fb, hipMemcpyHostToDevice, cs));
+            h->next_slot = slot;
+            rc = pad_on_device ? rrv_transfer_frames_device(h, st.d_in, nb, H, W, st.d_out) : rrv_transfer_batch_device(h, st.d_in, nb, H, W, st.d_out);
+            if (rc != RRV_OK) break;
+            HIPCHK(hipMemcpyAsync(out_pin ? (void*)out : (void*)st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, cs));
+            HIPCHK(hipStreamSynchronize(cs));
+            if (!out_pin) host_copy(out, st.pin_out, (size_t)nb * fb * sizeof(float));
+            h->next_slot = 0;
+            return RRV_OK;
+        }
         if (reuse) HIPCHK(hipStreamWaitEvent(h->copy_in, st.k_done, 0));       // the kernels of k-4 have read d_in
         HIPCHK(hipMemcpyAsync(st.d_in, src, (size_t)nb * fb, hipMemcpyHostToDevice, h->copy_in));
         HIPCHK(hipEventRecord(st.in_done, h->copy_in));

@@ -110,7 +110,7 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     }
     {   // row-split kernel: per-phase cycles (wave averages)
         long long* dbg; CK(hipMalloc(&dbg, (size_t)256 * 8 * 6 * 8));
-        ConvP q = p; q.n1 = (const float*)dbg; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
+        ConvP q = p; q.dbg = dbg; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
         int items = q.tiles_x * q.tiles_y * q.B * (q.Cout / 32);
         dim3 grid(items < 256 ? items : 256, 1);
         CK(hipFuncSetAttribute((const void*)conv_wino_split_k<E_RELU, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES));
@@ -152,7 +152,7 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     }
     {   // Winograd per-phase cycles (wave averages)
         long long* dbg; CK(hipMalloc(&dbg, (size_t)256 * 8 * 6 * 8));
-        ConvP q = p; q.n1 = (const float*)dbg; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
+        ConvP q = p; q.dbg = dbg; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
         int items = q.tiles_x * q.tiles_y * q.B * (q.Cout / 32);
         dim3 grid(items < 256 ? items : 256, 1);
         CK(hipFuncSetAttribute((const void*)conv_wino_k<E_RELU, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeo<4, 0>::SMEM)));
@@ -171,7 +171,7 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     {   // per-wave timeline (s_memtime): loop time vs epilogue time, and the spread of WG start times
         const int nw = p.tiles_x * p.tiles_y * B * (Cout / BN) * 4;
         long long* dbg; CK(hipMalloc(&dbg, (size_t)nw * 4 * 8));
-        ConvP q = p; q.n1 = (const float*)dbg;
+        ConvP q = p; q.dbg = dbg;
         dim3 grid(p.tiles_x * p.tiles_y * p.B, p.Cout / BN);
         hipLaunchKernelGGL((conv_mfma_k<BN, 9, E_RELU, 16>), grid, dim3(256), 0, 0, q);
         CK(hipDeviceSynchronize());
