@@ -70,6 +70,16 @@ int rrv_add(rrv_handle h, const uint8_t* frame_bgr, int H, int W);
  * frames that records the saved statistics / dynamic filters for every prepared style. */
 int rrv_compute(rrv_handle h);
 
+/* Memory policy of rrv_compute.  Decoder.compute as written keeps every sampled frame's decoder activations resident
+ * (O(B * 64 * H * W) floats at the last level; the reference authors' own long-sequence sketch streams them through a
+ * disk cache, test/style_network.py:597-624).  When that workspace would exceed `bytes` (default 64 GiB) rrv_compute
+ * STREAMS instead: one sync point (normalisation layer / filter prediction) at a time, groups of G frames re-run the
+ * decoder prefix from their relu4_1 features and contribute partial statistics (sum, centred square sum, min, max;
+ * pairwise merge in fp64) — workspace = one group, independent of B; the state blob equals the resident one to
+ * rounding.  rrv_last_compute_info reports what the last rrv_compute did. */
+int rrv_set_workspace_cap(rrv_handle h, size_t bytes);
+int rrv_last_compute_info(rrv_handle h, int* groups, int* group_size, size_t* workspace_bytes);
+
 /* The saved state of one style as a flat blob (what an RCCL broadcast ships to the other
  * ranks, and what the golden fixtures compare).  n must be RRV_STATE_FLOATS. */
 int rrv_get_state(rrv_handle h, float* out, int n, int style_id);

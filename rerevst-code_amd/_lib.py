@@ -25,6 +25,8 @@ SYMBOLS = {
     "rrv_clean": (C.c_int, [C.c_void_p]),
     "rrv_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_compute": (C.c_int, [C.c_void_p]),
+    "rrv_set_workspace_cap": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rrv_last_compute_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "rrv_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_transfer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

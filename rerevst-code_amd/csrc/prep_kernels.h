@@ -221,6 +221,61 @@ __global__ __launch_bounds__(256) void chan_final_k(const double* __restrict__ p
     }
 }
 
+// ---- streaming statistics (compute() over groups of sampled frames) -------------------------------------------
+// Per channel the running (mean, M2 = centred sum of squares, min, max) of everything seen so far lives in
+// acc[4][C] doubles.  A group contributes its own two-pass partials — part0: sums, part1: squares about the group's
+// fp32 mean m32, min, max — which are merged with the pairwise update of Chan et al.:
+//   d = mean_b - mean_a;  mean = mean_a + d n_b/n;  M2 = M2_a + M2_b + d^2 n_a n_b/n       (n = n_a + n_b)
+// (M2_b about the exact group mean = sum (x - m32)^2 - n_b (mean_b - m32)^2).  part1 == nullptr: means only.
+// launch: C/16 blocks of 256 threads, as chan_final_k.
+__global__ __launch_bounds__(256) void chan_merge_k(const double* __restrict__ part0, const double* __restrict__ part1, int nblk, int C,
+                                                    double n_b, const float* __restrict__ m32, double* __restrict__ acc, double n_a) {
+    __shared__ double s_s[16][16], s_q[16][16];
+    __shared__ float s_mn[16][16], s_mx[16][16];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0, q = 0.0;
+    float mn = 3.4e38f, mx = -3.4e38f;
+    if (c < C)
+        for (int k = kl; k < nblk; k += 16) {
+            s += part0[(size_t)k * 3 * C + c];
+            if (part1) {
+                const double* o = part1 + (size_t)k * 3 * C;
+                q += o[c];
+                mn = fminf(mn, (float)o[C + c]);
+                mx = fmaxf(mx, (float)o[2 * C + c]);
+            }
+        }
+    s_s[kl][cl] = s; s_q[kl][cl] = q; s_mn[kl][cl] = mn; s_mx[kl][cl] = mx;
+    __syncthreads();
+    if (kl != 0 || c >= C) return;
+    for (int k = 1; k < 16; ++k) { s += s_s[k][cl]; q += s_q[k][cl]; mn = fminf(mn, s_mn[k][cl]); mx = fmaxf(mx, s_mx[k][cl]); }
+    const double mean_b = s / n_b;
+    double M2_b = 0.0;
+    if (part1) { const double e = mean_b - (double)m32[c]; M2_b = q - n_b * e * e; if (M2_b < 0.0) M2_b = 0.0; }
+    if (n_a == 0.0) {
+        acc[c] = mean_b; acc[C + c] = M2_b; acc[2 * C + c] = mn; acc[3 * C + c] = mx;
+    } else {
+        const double n = n_a + n_b, d = mean_b - acc[c];
+        acc[c] += d * (n_b / n);
+        acc[C + c] += M2_b + d * d * (n_a * n_b / n);
+        acc[2 * C + c] = fmin(acc[2 * C + c], (double)mn);
+        acc[3 * C + c] = fmax(acc[3 * C + c], (double)mx);
+    }
+}
+
+// mode 0: out[c] = mean;  mode 1: out = norm params [4][C] (mean, rsqrt(M2/N + 1e-8), (min-mean) rstd, (max-mean) rstd),
+// with the same fp32 roundings as chan_final_k.
+__global__ void chan_finish_k(const double* __restrict__ acc, int C, double N, int mode, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float m = (float)acc[c];
+    if (mode == 0) { out[c] = m; return; }
+    const float var = (float)(acc[C + c] / N) + 1e-8f;
+    const float r = 1.0f / sqrtf(var);
+    out[c] = m; out[C + c] = r; out[2 * C + c] = ((float)acc[2 * C + c] - m) * r; out[3 * C + c] = ((float)acc[3 * C + c] - m) * r;
+}
+
 // ---- pointwise step of the preparation pass (valid pixels only, ring preserved) -------
 struct PointP {
     const float* x; float* y;      // y may alias x

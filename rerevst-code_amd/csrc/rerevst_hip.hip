@@ -119,6 +119,11 @@ struct rrv_ctx {
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
     float* d_outf = nullptr; size_t d_outf_cap = 0;
     double* stat_part = nullptr; float* stat_mean = nullptr;      // chan_stats scratch
+    // streaming compute(): second partial buffer, two running accumulators [4][512] doubles, frame 0's filter residuals
+    double* stat_part2 = nullptr; double* stat_acc = nullptr;
+    Tens stream_u[3], stream_grp, stream_f0;
+    size_t ws_cap = (size_t)64 << 30;          // preparation-pass workspace above which compute() streams groups of frames
+    int last_groups = 0, last_group_size = 0; size_t last_ws_bytes = 0;
     PrepPlan prep;
     // frames handed to rrv_add wait here (uint8, HBM) and are encoded together, 8 per encoder launch, when their
     // features are first needed (rrv_compute): the encoder at B = 1 runs at a fraction of its batched rate
@@ -767,6 +772,175 @@ int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = 
     return rc;
 }
 
+// ---- streaming preparation pass ------------------------------------------------------------------------------
+// Decoder.compute keeps every sampled frame's activations resident: O(B * 64 * H * W) at the last level (the reference
+// authors' own long-sequence sketch streams them through a disk cache layer by layer: test/style_network.py:597-624).
+// Here the pass is re-ordered by SYNC POINT instead: the 11 normalisation layers and the 3 filter predictions are the
+// only places where frames interact (a mean / centred square sum / min / max over (B,H,W)), and quirk Q1 — only
+// frame 0's KernelFilter residual exists and is broadcast to every frame — means nothing else crosses frames.  For
+// each of the 14 sync points every GROUP of G frames re-runs the decoder prefix from its relu4_1 features with the
+// statistics already known, contributes its partial (chan_merge_k) and is dropped.  Workspace = one group, whatever B.
+size_t tens_bytes(int B, int H, int W, int C) { return ((size_t)B * (H + 2) * (W + 2) * C + (size_t)20 * (W + 2 + 20) * C) * sizeof(float); }
+size_t prep_bytes(int B, int hh, int ww, int sH, int sW) {      // what prep_plan allocates (+ the [B,hh,ww,512] content batch)
+    size_t n = 2 * tens_bytes(B, hh, ww, 512) + tens_bytes(1, sH, sW, 512) + tens_bytes(B, hh, ww, 32) + tens_bytes(1, sH, sW, 32) +
+               tens_bytes(1, hh, ww, 32) + tens_bytes(1, hh, ww, 512) + tens_bytes(B, hh, ww, 512);
+    const int cout[3] = {256, 128, 64};
+    for (int k = 0, H = hh, W = ww; k < 3; ++k, H *= 2, W *= 2) n += tens_bytes(B, H, W, cout[k]) + 2 * tens_bytes(B, 2 * H, 2 * W, cout[k]);
+    return n;
+}
+
+// one group's partial statistics of tensor t merged into accumulator `slot` (n_a elements per channel seen before)
+int chan_stats_group(rrv_handle h, const Tens& t, bool want_m2, int slot, double n_a) {
+    const long npix = (long)t.B * t.H * t.W;
+    int nblk = (int)((npix + 255) / 256);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    const int ppb = (int)((npix + nblk - 1) / nblk);
+    if (t.C > 512) return fail(h, RRV_E_ARG, "chan_stats: more than 512 channels");
+    if (!h->stat_part) HIPCHK(hipMalloc((void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
+    if (!h->stat_part2) HIPCHK(hipMalloc((void**)&h->stat_part2, (size_t)1024 * 3 * 512 * sizeof(double)));
+    if (!h->stat_mean) HIPCHK(hipMalloc((void**)&h->stat_mean, 512 * sizeof(float)));
+    if (!h->stat_acc) HIPCHK(hipMalloc((void**)&h->stat_acc, (size_t)2 * 4 * 512 * sizeof(double)));
+    double* acc = h->stat_acc + (size_t)slot * 4 * 512;
+    StatP sp{t.p, t.B, t.H, t.W, t.C, nullptr, h->stat_part, 0, ppb};
+    const int fb = (t.C + 15) / 16;
+    hipLaunchKernelGGL(chan_stat_k, dim3(nblk), dim3(256), 0, h->stream, sp);
+    if (want_m2) {
+        hipLaunchKernelGGL(chan_final_k, dim3(fb), dim3(256), 0, h->stream, (const double*)h->stat_part, nblk, t.C, (double)npix, 0, (const float*)nullptr, h->stat_mean);
+        sp.pass = 1; sp.mean = h->stat_mean; sp.part = h->stat_part2;
+        hipLaunchKernelGGL(chan_stat_k, dim3(nblk), dim3(256), 0, h->stream, sp);
+    }
+    hipLaunchKernelGGL(chan_merge_k, dim3(fb), dim3(256), 0, h->stream, (const double*)h->stat_part, want_m2 ? (const double*)h->stat_part2 : (const double*)nullptr,
+                       nblk, t.C, (double)npix, (const float*)h->stat_mean, acc, n_a);
+    HIPCHK(hipGetLastError());
+    return RRV_OK;
+}
+int chan_stats_finish(rrv_handle h, int slot, int C, double N, int mode, float* out) {
+    hipLaunchKernelGGL(chan_finish_k, dim3((C + 255) / 256), dim3(256), 0, h->stream, (const double*)(h->stat_acc + (size_t)slot * 4 * 512), C, N, mode, out);
+    HIPCHK(hipGetLastError());
+    return RRV_OK;
+}
+
+struct BlkDesc { const char* name; int cout, n1, n2, nada, sty; };
+const BlkDesc BLKS[3] = {{"slice4", 256, N_S4N1, N_S4N2, N_DEC2, 2}, {"slice3", 128, N_S3N1, N_S3N2, N_DEC3, 1}, {"slice2", 64, N_S2N1, N_S2N2, N_DEC4, 0}};
+enum { ST_NORM0 = 0, ST_FILTER = 1 /* +f */, ST_NORM1 = 4, ST_BLOCKS = 5 /* +3k: n1, n2, nada */, ST_COUNT = 14 };
+
+// Decoder.compute prefix of one group (`grp`: nb raw relu4_1 features) up to sync point `stage`, whose partial
+// statistics are merged (n_a = elements per channel already merged at that stage's resolution: frames_before * H * W).
+int stream_prefix(rrv_handle h, int sid, const Tens& grp, int nb, int stage, int frames_before) {
+    StyleState& S = h->styles[sid];
+    float* st = S.blob;
+    PrepPlan& P = h->prep;
+    const int hh = grp.H, ww = grp.W;
+    auto view = [&](Tens& t) { Tens v = t; v.B = nb; return v; };
+    Tens g = grp; g.B = nb;
+    if (stage == ST_NORM0) return chan_stats_group(h, g, true, 0, (double)frames_before * hh * ww);
+    Tens cn = view(P.cn), nxt = view(P.nxt), t32 = view(P.t32);
+    RCHK(pointwise(h, g, cn, st + SL.norm[N_DEC0], st + SL.norm[N_DEC0] + 512, false, nullptr, 0, nullptr, nullptr));
+    Tens* cur = &cn; Tens* other = &nxt;
+    for (int f = 0; f < 3; ++f) {
+        if (stage == ST_FILTER + f) {
+            char pre[64];
+            snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
+            for (int gi = 0; gi < 2; ++gi) {       // FilterPredictor.compute (:161-172): mean over (B,HW) of down_sample(content)
+                ConvCall c{cur, &t32, &h->conv[std::string(pre) + (gi ? ".F2" : ".F1") + ".down_sample.0"], hh, ww}; c.B = nb; RCHK(conv(h, c));
+                RCHK(chan_stats_group(h, t32, false, gi, (double)frames_before * hh * ww));
+            }
+            return RRV_OK;
+        }
+        RCHK(pointwise(h, *cur, *other, nullptr, nullptr, false, &h->stream_u[f], 1, nullptr, nullptr));   // + frame 0's residual (Q1)
+        Tens* t = cur; cur = other; other = t;
+    }
+    if (stage == ST_NORM1) return chan_stats_group(h, *cur, true, 0, (double)frames_before * hh * ww);
+    RCHK(pointwise(h, *cur, *cur, st + SL.norm[N_DEC1], st + SL.norm[N_DEC1] + 512, false, nullptr, 0, st + SL.sty[3], st + SL.sty[3] + 512));
+    Tens in = *cur;
+    for (int k = 0; k < 3; ++k) {
+        const BlkDesc& b = BLKS[k];
+        const std::string p = std::string("Decoder.") + b.name;
+        Tens xs = view(P.xs[k]), a = view(P.a[k]), o = view(P.o[k]);
+        const int H2 = in.H * 2, W2 = in.W * 2;
+        const double n_a = (double)frames_before * H2 * W2;
+        ConvCall c;
+        c = ConvCall{&in, &a, &h->conv[p + ".conv1"], H2, W2}; c.B = nb; c.ups = true; c.epi = E_LRELU; RCHK(conv(h, c));
+        if (stage == ST_BLOCKS + 3 * k) return chan_stats_group(h, a, true, 0, n_a);
+        RCHK(pointwise(h, a, a, st + SL.norm[b.n1], st + SL.norm[b.n1] + b.cout, false, nullptr, 0, nullptr, nullptr));
+        c = ConvCall{&a, &o, &h->conv[p + ".conv2"], H2, W2}; c.B = nb; c.epi = E_LRELU; RCHK(conv(h, c));
+        if (stage == ST_BLOCKS + 3 * k + 1) return chan_stats_group(h, o, true, 0, n_a);
+        c = ConvCall{&in, &xs, &h->conv[p + ".conv_shortcut"], in.H, in.W}; c.B = nb; RCHK(conv(h, c));
+        RCHK(pointwise(h, o, o, st + SL.norm[b.n2], st + SL.norm[b.n2] + b.cout, false, &xs, 2, nullptr, nullptr));
+        if (stage == ST_BLOCKS + 3 * k + 2) return chan_stats_group(h, o, true, 0, n_a);
+        RCHK(pointwise(h, o, o, st + SL.norm[b.nada], st + SL.norm[b.nada] + b.cout, false, nullptr, 0, st + SL.sty[b.sty], st + SL.sty[b.sty] + b.cout));
+        in = o;
+    }
+    return fail(h, RRV_E_ARG, "stream_prefix: no such stage");
+}
+
+// Decoder.compute for one style over h->patches in groups of G frames
+int compute_style_streaming(rrv_handle h, int sid, int G) {
+    StyleState& S = h->styles[sid];
+    float* st = S.blob;
+    const int B = (int)h->patches.size(), hh = h->patch_h, ww = h->patch_w;
+    RCHK(prep_plan(h, G, hh, ww, S.map.H, S.map.W));
+    PrepPlan& P = h->prep;
+    RCHK(talloc(h, &h->stream_grp, G, hh, ww, 512));
+    RCHK(talloc(h, &h->stream_f0, 1, hh, ww, 512));
+    for (int f = 0; f < 3; ++f) RCHK(talloc(h, &h->stream_u[f], 1, hh, ww, 512));
+    const size_t img = h->stream_grp.img_floats();
+    auto body = [&]() -> int {
+        // normalized_style (:397) for the filter predictions
+        RCHK(pointwise(h, S.map, P.sn, st + SL.sty[3], st + SL.sty[3] + 512, true, nullptr, 0, nullptr, nullptr));
+        for (int stage = 0; stage < ST_COUNT; ++stage) {
+            for (int g0 = 0; g0 < B; g0 += G) {
+                const int nb = B - g0 < G ? B - g0 : G;
+                for (int b = 0; b < nb; ++b)
+                    HIPCHK(hipMemcpyAsync(h->stream_grp.p + (size_t)b * img, h->patches[g0 + b], img * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+                RCHK(stream_prefix(h, sid, h->stream_grp, nb, stage, g0));
+            }
+            // the sync point: every frame has contributed
+            if (stage == ST_NORM0) {
+                RCHK(chan_stats_finish(h, 0, 512, (double)B * hh * ww, 1, st + SL.norm[N_DEC0]));
+            } else if (stage >= ST_FILTER && stage < ST_FILTER + 3) {
+                const int f = stage - ST_FILTER;
+                char pre[64];
+                snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
+                for (int gi = 0; gi < 2; ++gi) {
+                    RCHK(chan_stats_finish(h, gi, 32, (double)B * hh * ww, 0, P.cmean));
+                    ConvCall cs{&P.sn, &P.ts32, &h->conv[std::string(pre) + (gi ? ".F2" : ".F1") + ".down_sample.0"], P.sn.H, P.sn.W}; RCHK(conv(h, cs));
+                    RCHK(chan_stats(h, P.ts32, 0, P.smean));
+                    hipLaunchKernelGGL(fc_filter_k, dim3(4), dim3(256), 0, h->stream, (const float*)h->fc_w[2 * f + gi], (const float*)h->fc_b[2 * f + gi],
+                                       (const float*)P.cmean, (const float*)P.smean, st + SL.filt[2 * f + gi]);
+                    HIPCHK(hipGetLastError());
+                }
+                RCHK(fold_filters(h, st, f));
+                h->active_src = -1;
+                // KernelFilter.compute (:223-230): frame 0 alone passes through apply_filter; its residual u_f is what every frame receives (Q1)
+                HIPCHK(hipMemcpyAsync(h->stream_f0.p, h->patches[0], img * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+                Tens cn0 = P.cn; cn0.B = 1;
+                RCHK(pointwise(h, h->stream_f0, cn0, st + SL.norm[N_DEC0], st + SL.norm[N_DEC0] + 512, false, nullptr, 0, nullptr, nullptr));
+                for (int f2 = 0; f2 < f; ++f2) RCHK(pointwise(h, cn0, cn0, nullptr, nullptr, false, &h->stream_u[f2], 1, nullptr, nullptr));
+                ConvCall c{&cn0, &P.d32, &h->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
+                ConvCall cu{&P.d32, &h->stream_u[f], &h->fold_up[f], hh, ww}; RCHK(conv(h, cu));
+            } else if (stage == ST_NORM1) {
+                RCHK(chan_stats_finish(h, 0, 512, (double)B * hh * ww, 1, st + SL.norm[N_DEC1]));
+            } else {
+                const int k = (stage - ST_BLOCKS) / 3, w = (stage - ST_BLOCKS) % 3;
+                const BlkDesc& b = BLKS[k];
+                const double N = (double)B * (hh << (k + 1)) * (ww << (k + 1));
+                RCHK(chan_stats_finish(h, 0, b.cout, N, 1, st + SL.norm[w == 0 ? b.n1 : (w == 1 ? b.n2 : b.nada)]));
+            }
+        }
+        return RRV_OK;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(h->stream);
+    prep_free(h);
+    tfree(&h->stream_grp); tfree(&h->stream_f0);
+    for (int f = 0; f < 3; ++f) tfree(&h->stream_u[f]);
+    h->active_src = -1;
+    if (rc == RRV_OK) S.computed = true;
+    return rc;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -830,6 +1004,8 @@ int rrv_destroy(rrv_handle h) {
     if (h->pend_u8) (void)hipFree(h->pend_u8);
     if (h->stat_part) (void)hipFree(h->stat_part);
     if (h->stat_mean) (void)hipFree(h->stat_mean);
+    if (h->stat_part2) (void)hipFree(h->stat_part2);
+    if (h->stat_acc) (void)hipFree(h->stat_acc);
     for (float* q : {h->first_w[0], h->first_w[1], h->first_b[0], h->first_b[1], h->first_wg}) if (q) (void)hipFree(q);
     for (auto& st : h->hstage) {
         if (st.pin_in) (void)hipHostFree(st.pin_in);
@@ -1027,17 +1203,28 @@ int rrv_compute(rrv_handle h) {
     int nprep = 0;
     for (StyleState& s : h->styles) nprep += s.prepared ? 1 : 0;
     if (!nprep) return fail(h, RRV_E_STATE, "compute: prepare_style has not been called");
-    Tens content;
     const int B = (int)h->patches.size();
-    RCHK(talloc(h, &content, B, h->patch_h, h->patch_w, 512));
-    for (int b = 0; b < B; ++b)
-        HIPCHK(hipMemcpyAsync(content.p + (size_t)b * content.img_floats(), h->patches[b], content.img_floats() * sizeof(float),
-                              hipMemcpyDeviceToDevice, h->stream));
+    int sH = 0, sW = 0;
+    for (StyleState& s : h->styles) if (s.prepared) { sH = s.map.H > sH ? s.map.H : sH; sW = s.map.W > sW ? s.map.W : sW; }
     int rc = RRV_OK, first = -1;
-    for (int s = 0; s < RRV_MAX_STYLES && rc == RRV_OK; ++s)
-        if (h->styles[s].prepared) { rc = compute_style(h, s, content); if (first < 0) first = s; }
-    (void)hipStreamSynchronize(h->stream);
-    tfree(&content);
+    if (prep_bytes(B, h->patch_h, h->patch_w, sH, sW) <= h->ws_cap) {      // everything resident (Decoder.compute as written)
+        Tens content;
+        RCHK(talloc(h, &content, B, h->patch_h, h->patch_w, 512));
+        for (int b = 0; b < B; ++b)
+            HIPCHK(hipMemcpyAsync(content.p + (size_t)b * content.img_floats(), h->patches[b], content.img_floats() * sizeof(float),
+                                  hipMemcpyDeviceToDevice, h->stream));
+        for (int s = 0; s < RRV_MAX_STYLES && rc == RRV_OK; ++s)
+            if (h->styles[s].prepared) { rc = compute_style(h, s, content); if (first < 0) first = s; }
+        (void)hipStreamSynchronize(h->stream);
+        tfree(&content);
+        h->last_groups = 1; h->last_group_size = B; h->last_ws_bytes = prep_bytes(B, h->patch_h, h->patch_w, sH, sW);
+    } else {                                                                // groups of G frames, one sync point at a time
+        int G = 1;
+        while (G < B && prep_bytes(G + 1, h->patch_h, h->patch_w, sH, sW) <= h->ws_cap) ++G;
+        for (int s = 0; s < RRV_MAX_STYLES && rc == RRV_OK; ++s)
+            if (h->styles[s].prepared) { rc = compute_style_streaming(h, s, G); if (first < 0) first = s; }
+        h->last_groups = (B + G - 1) / G; h->last_group_size = G; h->last_ws_bytes = prep_bytes(G, h->patch_h, h->patch_w, sH, sW);
+    }
     if (rc != RRV_OK) return rc;
     h->active_src = -1;
     return activate_state(h, first);
@@ -1405,6 +1592,19 @@ int rrv_set_pipeline(rrv_handle h, int n_slots) {
     RCHK(sync_all(h));
     h->n_slots = n_slots;
     h->next_slot = 0;
+    return RRV_OK;
+}
+
+int rrv_set_workspace_cap(rrv_handle h, size_t bytes) {
+    if (!h || !bytes) return RRV_E_ARG;
+    h->ws_cap = bytes;
+    return RRV_OK;
+}
+int rrv_last_compute_info(rrv_handle h, int* groups, int* group_size, size_t* workspace_bytes) {
+    if (!h) return RRV_E_ARG;
+    if (groups) *groups = h->last_groups;
+    if (group_size) *group_size = h->last_group_size;
+    if (workspace_bytes) *workspace_bytes = h->last_ws_bytes;
     return RRV_OK;
 }
 

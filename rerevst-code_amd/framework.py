@@ -103,6 +103,17 @@ class Stylization():
         self._global_only("compute")
         self._chk(self._lib.rrv_compute(self._h))
 
+    def set_workspace_cap(self, nbytes):
+        """compute() keeps all sampled frames' activations resident while they fit `nbytes` (default 64 GiB); beyond
+        that it streams groups of frames one synchronisation point at a time (workspace independent of the frame count)."""
+        self._chk(self._lib.rrv_set_workspace_cap(self._h, int(nbytes)))
+
+    def last_compute_info(self):
+        """(groups, frames per group, workspace bytes) of the last compute()."""
+        g, n, b = C.c_int(), C.c_int(), C.c_size_t()
+        self._chk(self._lib.rrv_last_compute_info(self._h, C.byref(g), C.byref(n), C.byref(b)))
+        return g.value, n.value, b.value
+
     def clean(self):
         self._global_only("clean")
         self._chk(self._lib.rrv_clean(self._h))

@@ -7,7 +7,7 @@ import importlib
 import numpy as np
 import pytest
 
-from conftest import (load_golden, assert_state_close, assert_pre_close, IMG_ATOL)
+from conftest import (load_golden, golden_inputs, assert_state_close, assert_pre_close, IMG_ATOL)
 
 pytestmark = pytest.mark.gpu
 
@@ -115,4 +115,58 @@ def test_compute_with_many_sampled_frames_vs_oracle(B, hw, pkg, weights, oracle)
     assert_state_close(s.get_state(), o.get_state(), "B=%d" % B)
     frame = oracle.reflect_pad(pkg.synth_frame(B + 3, H, W, kind="smooth", seed=70), oracle.padded_size(H), oracle.padded_size(W))
     assert np.abs(s.transfer(frame) - o.transfer(frame)).max() <= IMG_ATOL
+    s.close()
+
+
+def test_streaming_compute_equals_resident_and_reference(pkg, weights, oracle):
+    """rrv_compute with a workspace cap below one batch streams groups of frames, one sync point at a time
+    (reference sketch test/style_network.py:597-624): same state blob as the resident pass —
+    G = 1 (every frame its own group), G = 2 with a ragged last group — and as the reference golden."""
+    g = load_golden("global_a")
+    style, frames, ids, tid = golden_inputs(pkg, g)
+    s = pkg.Stylization(weights, cuda=True)
+    s.prepare_style(style)
+    def run(cap):
+        s.clean()
+        if cap:
+            s.set_workspace_cap(cap)
+        for i in ids:
+            s.add(frames[i])
+        s.compute()
+        return s.get_state(), s.last_compute_info()
+    res, info = run(None)
+    assert info[0] == 1 and info[1] == len(ids)
+    st1, info1 = run(1)                                   # cap of one byte: G = 1
+    assert info1[0] == len(ids) and info1[1] == 1
+    assert_state_close(st1, res, "streaming G=1 vs resident")
+    assert_state_close(st1, g["state"], "streaming G=1 vs reference")
+    st2, info2 = run((info1[2] + info[2]) // 2)           # room for two of the three frames: groups of 2, the last one ragged
+    assert info2[1] == 2 and info2[0] == 2
+    assert_state_close(st2, res, "streaming G=2 vs resident")
+    # the per-frame path with the streamed state
+    out = s.transfer(oracle.reflect_pad(frames[tid], 192, 192))
+    assert np.abs(out - g["out"]).max() <= IMG_ATOL
+    s.close()
+
+
+def test_streaming_compute_b150_at_512_workspace_independent_of_b(pkg, weights):
+    """BASELINE config 4's preparation: 150 sampled 512x512 frames.  Resident: ~42 GB of activations.  With a 6 GiB cap
+    the pass streams; the workspace is the same for 40 and for 150 sampled frames, and the state equals the resident one."""
+    style = pkg.synth_style(128, 128, kind="smooth", seed=7)
+    s = pkg.Stylization(weights, cuda=True)
+    s.prepare_style(style)
+    def run(n, cap):
+        s.clean()
+        s.set_workspace_cap(cap)
+        for i in range(n):
+            s.add(pkg.synth_frame(i % 24, 512, 512, kind="smooth", seed=80 + i // 24))
+        s.compute()
+        return s.get_state(), s.last_compute_info()
+    res, info = run(150, 1 << 40)
+    assert info[0] == 1 and info[2] > 30 * 2 ** 30
+    st, i150 = run(150, 6 * 2 ** 30)
+    assert i150[0] > 1 and i150[2] <= 6 * 2 ** 30
+    assert_state_close(st, res, "streaming B=150 vs resident")
+    _, i40 = run(40, 6 * 2 ** 30)
+    assert i40[1] == i150[1] and i40[2] == i150[2]        # same group size, same workspace: independent of B
     s.close()
