@@ -29,7 +29,8 @@ enum {
     RRV_E_HIP = -2,        /* HIP runtime error */
     RRV_E_WEIGHTS = -3,    /* unknown key, wrong shape, or weights incomplete */
     RRV_E_STATE = -4,      /* transfer before compute()/set_state, compute with no frames, ... */
-    RRV_E_NOMEM = -5
+    RRV_E_NOMEM = -5,
+    RRV_E_DEBUG = -6       /* bounds-checked debug mode found a store outside a tensor's valid region */
 };
 
 /* Floats in the per-style shared-state blob: 11 norm layers x {mean,rstd,lo,hi}[C]
@@ -164,6 +165,16 @@ int rrv_host_alloc(size_t bytes, void** out);
 int rrv_host_free(void* p);
 int rrv_host_register(void* p, size_t bytes);
 int rrv_host_unregister(void* p);
+
+/* Bounds-checked debug mode (also RRV_DEBUG=<level> in the environment at rrv_create).  Every activation tensor is
+ * allocated between two 64 KB guard bands filled with a canary; level 1 synchronises and checks after every API call,
+ * level 2 after every kernel launch (an asynchronous fault or a violation is reported with the kernel's name):
+ * guard bands intact, the one-pixel zero ring and the slack rows of every tensor still zero (the kernels rely on both
+ * and must never store outside the valid pixels).  A violation returns RRV_E_DEBUG.  Changing the level drops the
+ * workspaces (saved state and prepared styles are kept).  rrv_debug_selftest plants one ring store and one guard-band
+ * store and returns RRV_OK only if the checker reports both. */
+int rrv_set_debug(rrv_handle h, int level);
+int rrv_debug_selftest(rrv_handle h);
 
 /* Per-launch timing with HIP events recorded on the handle's own stream.
  * rrv_profile_begin() clears the log and starts bracketing every kernel launch with

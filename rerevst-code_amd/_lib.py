@@ -50,6 +50,8 @@ SYMBOLS = {
     "rrv_host_free": (C.c_int, [C.c_void_p]),
     "rrv_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rrv_host_unregister": (C.c_int, [C.c_void_p]),
+    "rrv_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
+    "rrv_debug_selftest": (C.c_int, [C.c_void_p]),
     "rrv_profile_begin": (C.c_int, [C.c_void_p]),
     "rrv_profile_end": (C.c_int, [C.c_void_p]),
     "rrv_profile_count": (C.c_int, [C.c_void_p]),

@@ -8,6 +8,7 @@
 #include <thread>
 #include <stdio.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,7 @@ const StateLayout SL;
 
 struct Tens {
     float* p = nullptr;
+    float* base = nullptr;            // debug mode: start of the allocation (guard band in front of p)
     int B = 0, H = 0, W = 0, C = 0;
     size_t img_floats() const { return (size_t)(H + 2) * (W + 2) * C; }
 };
@@ -136,6 +138,7 @@ struct rrv_ctx {
                        size_t cap = 0, pcap = 0; hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr; } hstage[4];
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     int n_cus = 256;
+    int debug = 0;                    // rrv_set_debug / RRV_DEBUG: 1 = sync + check after every API call, 2 = after every kernel launch
     bool profiling = false;
     std::vector<ProfEntry> prof;
 };
@@ -170,14 +173,99 @@ int dalloc(rrv_handle h, float** p, size_t floats, bool zero = true) {
     return RRV_OK;
 }
 
+// ---- bounds-checked debug mode (rrv_set_debug) -------------------------------------------------------------------
+// Every ring-layout tensor is allocated between two guard bands filled with a canary; after every API call (level 1)
+// or every kernel launch (level 2) the stream is synchronised (an asynchronous fault is reported with the kernel's
+// name) and every live tensor of the handle is verified: guard bands intact, the one-pixel zero ring and the slack
+// rows behind the last image still zero (the kernels rely on both and must never store outside the valid pixels).
+constexpr size_t DBG_GUARD = 16384;                 // floats per guard band (64 KB)
+constexpr uint32_t DBG_CANARY = 0xDEADBEEFu;
+struct DbgRec { rrv_ctx* h; float* base; int B, H, W, C; size_t floats; };
+std::mutex g_dbg_mu;
+std::map<float*, DbgRec> g_dbg;
+
+__global__ void dbg_check_k(const float* base, const float* p, int B, int H, int W, int C, size_t floats, unsigned* counters) {
+    const uint32_t* gb = (const uint32_t*)base;
+    const uint32_t* u = (const uint32_t*)p;
+    const size_t img = (size_t)(H + 2) * (W + 2) * C;
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    unsigned bad_guard = 0, bad_ring = 0;
+    for (size_t i = tid; i < DBG_GUARD; i += nth) bad_guard += (gb[i] != DBG_CANARY) + (((const uint32_t*)(p + floats))[i] != DBG_CANARY);
+    // ring: rows 0 and H+1, columns 0 and W+1 of every image
+    const size_t ring_px = (size_t)2 * (W + 2) + (size_t)2 * H;
+    for (size_t i = tid; i < (size_t)B * ring_px * C; i += nth) {
+        const size_t c = i % C, r = (i / C) % ring_px, b = i / C / ring_px;
+        size_t y, x;
+        if (r < (size_t)(W + 2)) { y = 0; x = r; }
+        else if (r < (size_t)2 * (W + 2)) { y = H + 1; x = r - (W + 2); }
+        else { const size_t q = r - 2 * (W + 2); y = 1 + (q >> 1); x = (q & 1) ? W + 1 : 0; }
+        bad_ring += u[b * img + (y * (W + 2) + x) * C + c] != 0u;
+    }
+    for (size_t i = (size_t)B * img + tid; i < floats; i += nth) bad_ring += u[i] != 0u;     // slack behind the last image
+    if (bad_guard) atomicAdd(&counters[0], bad_guard);
+    if (bad_ring) atomicAdd(&counters[1], bad_ring);
+}
+__global__ void dbg_fill_k(uint32_t* p, size_t n, uint32_t v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+int debug_verify(rrv_handle h, const char* where) {
+    std::vector<DbgRec> recs;
+    std::vector<float*> ptrs;
+    {
+        std::lock_guard<std::mutex> lk(g_dbg_mu);
+        for (auto& kv : g_dbg) if (kv.second.h == h) { recs.push_back(kv.second); ptrs.push_back(kv.first); }
+    }
+    for (int i = 0; i < RRV_MAX_SLOTS; ++i) if (h->streams[i]) {
+        const hipError_t e = hipStreamSynchronize(h->streams[i]);
+        if (e != hipSuccess) return fail(h, RRV_E_HIP, std::string("debug: asynchronous fault after ") + where + ": " + hipGetErrorString(e));
+    }
+    if (recs.empty()) return RRV_OK;
+    unsigned* d_cnt = nullptr;
+    HIPCHK(hipMalloc((void**)&d_cnt, recs.size() * 2 * sizeof(unsigned)));
+    HIPCHK(hipMemset(d_cnt, 0, recs.size() * 2 * sizeof(unsigned)));
+    for (size_t i = 0; i < recs.size(); ++i)
+        hipLaunchKernelGGL(dbg_check_k, dim3(64), dim3(256), 0, h->streams[0], (const float*)recs[i].base, (const float*)ptrs[i], recs[i].B, recs[i].H, recs[i].W,
+                           recs[i].C, recs[i].floats, d_cnt + 2 * i);
+    std::vector<unsigned> cnt(recs.size() * 2);
+    HIPCHK(hipMemcpy(cnt.data(), d_cnt, cnt.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d_cnt);
+    for (size_t i = 0; i < recs.size(); ++i)
+        if (cnt[2 * i] || cnt[2 * i + 1]) {
+            char b[256];
+            snprintf(b, sizeof b, "debug: after %s tensor [%d,%d,%d,%d] has %u guard-band words overwritten and %u non-zero ring/slack words",
+                     where, recs[i].B, recs[i].H, recs[i].W, recs[i].C, cnt[2 * i], cnt[2 * i + 1]);
+            return fail(h, RRV_E_DEBUG, b);
+        }
+    return RRV_OK;
+}
+
+void tfree(Tens* t) {
+    if (t->base) {
+        { std::lock_guard<std::mutex> lk(g_dbg_mu); g_dbg.erase(t->p); }
+        (void)hipFree(t->base);
+    } else if (t->p) {
+        (void)hipFree(t->p);
+    }
+    t->p = nullptr; t->base = nullptr;
+}
+
 // ring-layout tensor; slack rows keep tile-overrun halo reads inside the allocation
 int talloc(rrv_handle h, Tens* t, int B, int H, int W, int C) {
-    if (t->p) { (void)hipFree(t->p); t->p = nullptr; }
+    tfree(t);
     t->B = B; t->H = H; t->W = W; t->C = C;
     const size_t slack = (size_t)20 * (W + 2 + 20) * C;
-    return dalloc(h, &t->p, (size_t)B * t->img_floats() + slack, true);
+    const size_t floats = (size_t)B * t->img_floats() + slack;
+    if (!h->debug) return dalloc(h, &t->p, floats, true);
+    HIPCHK(hipMalloc((void**)&t->base, (floats + 2 * DBG_GUARD) * sizeof(float)));
+    t->p = t->base + DBG_GUARD;
+    hipLaunchKernelGGL(dbg_fill_k, dim3(16), dim3(256), 0, h->stream, (uint32_t*)t->base, DBG_GUARD, DBG_CANARY);
+    hipLaunchKernelGGL(dbg_fill_k, dim3(16), dim3(256), 0, h->stream, (uint32_t*)(t->p + floats), DBG_GUARD, DBG_CANARY);
+    HIPCHK(hipMemsetAsync(t->p, 0, floats * sizeof(float), h->stream));
+    std::lock_guard<std::mutex> lk(g_dbg_mu);
+    g_dbg[t->p] = DbgRec{h, t->base, B, H, W, C, floats};
+    return RRV_OK;
 }
-void tfree(Tens* t) { if (t->p) (void)hipFree(t->p); t->p = nullptr; }
 
 template <typename F>
 int launch(rrv_handle h, const char* name, double flops, double bytes, F&& f, double flops_exec = -1.0) {
@@ -192,6 +280,11 @@ int launch(rrv_handle h, const char* name, double flops, double bytes, F&& f, do
         f();
     }
     HIPCHK(hipGetLastError());
+    if (h->debug >= 2) return debug_verify(h, name);
+    if (h->debug == 1) {
+        const hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return fail(h, RRV_E_HIP, std::string("debug: asynchronous fault in ") + name + ": " + hipGetErrorString(e));
+    }
     return RRV_OK;
 }
 
@@ -653,6 +746,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         HIPCHK(hipEventRecord(h->slot_ev[slot], h->stream));
         HIPCHK(hipStreamWaitEvent(h->caller_stream, h->slot_ev[slot], 0));
     }
+    if (h->debug) RCHK(debug_verify(h, "transfer"));
     return RRV_OK;
 }
 
@@ -763,7 +857,8 @@ int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = 
         }
         return RRV_OK;
     };
-    const int rc = body();
+    int rc = body();
+    if (rc == RRV_OK && h->debug) rc = debug_verify(h, "Decoder.compute");
     if (!frame_mode || rc != RRV_OK) {
         (void)hipStreamSynchronize(h->stream);
         prep_free(h);
@@ -931,7 +1026,8 @@ int compute_style_streaming(rrv_handle h, int sid, int G) {
         }
         return RRV_OK;
     };
-    const int rc = body();
+    int rc = body();
+    if (rc == RRV_OK && h->debug) rc = debug_verify(h, "Decoder.compute (streaming)");
     (void)hipStreamSynchronize(h->stream);
     prep_free(h);
     tfree(&h->stream_grp); tfree(&h->stream_f0);
@@ -975,7 +1071,55 @@ int rrv_create(int device, rrv_handle* out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
     }
+    if (const char* e = getenv("RRV_DEBUG")) h->debug = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     *out = h;
+    return RRV_OK;
+}
+
+static void free_plans(rrv_handle h) {
+    for (EncPlan* e : {&h->enc_frame[0], &h->enc_frame[1], &h->enc_frame[2], &h->enc_frame[3], &h->enc_add, &h->enc_style})
+        for (Tens* t : {&e->c11, &e->p1, &e->c21, &e->p2, &e->c31, &e->c32, &e->c33, &e->p3, &e->c41}) tfree(t);
+    for (DecPlan& d : h->dec) {
+        for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2}) tfree(t);
+        if (d.pre) { if (h->last_pre == d.pre) h->last_pre = nullptr; (void)hipFree(d.pre); d.pre = nullptr; }
+        d.B = d.H = d.W = 0;
+    }
+    prep_free(h);
+}
+
+int rrv_set_debug(rrv_handle h, int level) {
+    if (!h || level < 0 || level > 2) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    free_plans(h);          // workspaces are re-allocated with (or without) guard bands on next use; styles keep their maps
+    h->debug = level;
+    return RRV_OK;
+}
+
+__global__ void dbg_poke_k(float* p, long off) { p[off] = 1.0f; }
+// the checker checks itself: one store into a ring pixel and one into a guard band must both be reported
+int rrv_debug_selftest(rrv_handle h) {
+    if (!h) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    const int saved = h->debug;
+    h->debug = 2;
+    Tens t;
+    int rc = talloc(h, &t, 2, 8, 8, 64);
+    if (rc == RRV_OK) rc = debug_verify(h, "selftest (clean)");
+    int caught = 0;
+    if (rc == RRV_OK) {
+        hipLaunchKernelGGL(dbg_poke_k, dim3(1), dim3(1), 0, h->stream, t.p, (long)t.img_floats() + 5);       // ring pixel (0,0) of image 1
+        if (debug_verify(h, "selftest (ring)") == RRV_E_DEBUG) ++caught;
+        HIPCHK(hipMemsetAsync(t.p + t.img_floats(), 0, 64 * sizeof(float), h->stream));
+        hipLaunchKernelGGL(dbg_poke_k, dim3(1), dim3(1), 0, h->stream, t.p, -3L);                            // guard band in front
+        if (debug_verify(h, "selftest (guard)") == RRV_E_DEBUG) ++caught;
+    }
+    tfree(&t);
+    h->debug = saved;
+    if (rc != RRV_OK) return rc;
+    if (caught != 2) return fail(h, RRV_E_DEBUG, "debug selftest: a deliberate out-of-bounds store was not detected");
+    h->err.clear();
     return RRV_OK;
 }
 
@@ -993,14 +1137,10 @@ int rrv_destroy(rrv_handle h) {
     }
     for (float* p : h->patches) (void)hipFree(p);
     for (auto& f : h->features) if (f.p) (void)hipFree(f.p);
-    for (EncPlan* e : {&h->enc_frame[0], &h->enc_frame[1], &h->enc_frame[2], &h->enc_frame[3], &h->enc_add, &h->enc_style})
-        for (Tens* t : {&e->c11, &e->p1, &e->c21, &e->p2, &e->c31, &e->c32, &e->c33, &e->p3, &e->c41}) tfree(t);
-    for (DecPlan& d : h->dec)
-        for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2}) tfree(t);
+    free_plans(h);
     for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->d_outf) (void)hipFree(h->d_outf);
-    prep_free(h);
     if (h->pend_u8) (void)hipFree(h->pend_u8);
     if (h->stat_part) (void)hipFree(h->stat_part);
     if (h->stat_mean) (void)hipFree(h->stat_mean);
@@ -1130,6 +1270,7 @@ int rrv_prepare_style(rrv_handle h, const uint8_t* style, int Hs, int Ws, int si
     RCHK(talloc(h, &S.map, 1, e.c41.H, e.c41.W, 512));
     HIPCHK(hipMemcpyAsync(S.map.p, e.c41.p, e.c41.img_floats() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->debug) RCHK(debug_verify(h, "prepare_style"));
     S.prepared = true; S.computed = false;
     if (h->active_src == sid) h->active_src = -1;
     return RRV_OK;
@@ -1226,6 +1367,7 @@ int rrv_compute(rrv_handle h) {
         h->last_groups = (B + G - 1) / G; h->last_group_size = G; h->last_ws_bytes = prep_bytes(G, h->patch_h, h->patch_w, sH, sW);
     }
     if (rc != RRV_OK) return rc;
+    if (h->debug) RCHK(debug_verify(h, "compute"));
     h->active_src = -1;
     return activate_state(h, first);
 }

@@ -103,6 +103,13 @@ class Stylization():
         self._global_only("compute")
         self._chk(self._lib.rrv_compute(self._h))
 
+    def set_debug(self, level):
+        """Bounds-checked debug mode: 0 off, 1 verify guard bands / zero rings after every call, 2 after every kernel."""
+        self._chk(self._lib.rrv_set_debug(self._h, int(level)))
+
+    def debug_selftest(self):
+        self._chk(self._lib.rrv_debug_selftest(self._h))
+
     def set_workspace_cap(self, nbytes):
         """compute() keeps all sampled frames' activations resident while they fit `nbytes` (default 64 GiB); beyond
         that it streams groups of frames one synchronisation point at a time (workspace independent of the frame count)."""

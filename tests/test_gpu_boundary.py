@@ -180,3 +180,41 @@ dist.barrier(); dist.destroy_process_group()
     for i in range(9):
         np.testing.assert_array_equal(got[i], ref[i])
     s.close()
+
+
+def test_bounds_checked_debug_mode(pkg, weights, oracle):
+    """rrv_set_debug(2): guard bands around every activation tensor, zero-ring / slack verification and a stream
+    sync after EVERY kernel launch, over the whole flow on sizes with partial tiles everywhere; same bits as the
+    unchecked run, and the checker's self-test (a planted ring store and a planted guard-band store) must fire."""
+    style = pkg.synth_style(40, 56, kind="smooth", seed=11)
+    sampled = [pkg.synth_frame(i, 37, 53, kind="smooth", seed=50) for i in range(3)]
+    frame = pkg.synth_frame(9, 200, 136, kind="smooth", seed=50)
+    raw = [pkg.synth_frame(30 + i, 67, 33, kind="noise", seed=50) for i in range(3)]
+    def flow(level):
+        s = pkg.Stylization(weights, cuda=True, style_num=2)
+        s.set_debug(level)
+        if level:
+            s.debug_selftest()
+        s.prepare_style([style, style[::-1].copy()])
+        s.clean()
+        for f in sampled:
+            s.add(f)
+        s.compute()
+        outs = [s.get_state(0), s.get_state(1), s.transfer(frame), s.transfer_batch([frame] * 3), s.transfer_frames(raw),
+                s.transfer(frame, style_weight=[0.25, 0.75])]
+        s.set_workspace_cap(1)                      # the streaming preparation pass under the checker as well
+        s.clean()
+        for f in sampled:
+            s.add(f)
+        s.compute()
+        outs.append(s.get_state(0))
+        s.close()
+        fm = pkg.Stylization(weights, cuda=True, use_Global=False)
+        fm.set_debug(level)
+        fm.prepare_style(style)
+        outs.append(fm.transfer(frame))
+        fm.close()
+        return outs
+    plain, checked = flow(0), flow(2)
+    for a, b in zip(plain, checked):
+        np.testing.assert_array_equal(a, b)
