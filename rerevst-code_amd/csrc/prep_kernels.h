@@ -221,6 +221,165 @@ __global__ __launch_bounds__(256) void chan_final_k(const double* __restrict__ p
     }
 }
 
+// ---- one-pass statistics (frame mode: per-frame InstanceNorm, test/style_network_frame.py:39-43) ------------------
+// One read of the tensor.  Every thread accumulates sum(x - s) and sum((x - s)^2) in fp64 about its own first value s
+// (inside the data's range, so nothing cancels), turns them into (n, mean, M2) and the block merges its threads with the
+// pairwise update of Chan et al.; per block [n | mean | M2] x C doubles go to `part` ([nblk][3][C]).
+__global__ __launch_bounds__(256) void chan_stat1_k(const StatP p) {
+    __shared__ double s_n[256], s_mean[256][4], s_m2[256][4];
+    const int tid = threadIdx.x;
+    const int CQ = p.C >> 2;
+    const int Qb = CQ < 64 ? CQ : 64;
+    const int nsub = 256 / Qb;
+    const int ql = tid % Qb, sub = tid / Qb;
+    const long npix = (long)p.B * p.H * p.W;
+    const long p0 = (long)blockIdx.x * p.pix_per_blk;
+    long p1 = p0 + p.pix_per_blk;
+    if (p1 > npix) p1 = npix;
+    for (int cg = 0; cg < CQ; cg += Qb) {
+        const int c = 4 * (cg + ql);
+        double sd[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+        long n = 0;
+        if (sub < nsub) {
+            long q = p0 + sub;
+            int x = (int)(q % p.W);
+            long r = q / p.W;
+            int y = (int)(r % p.H);
+            long b = r / p.H;
+            for (; q < p1; q += nsub) {
+                const f32x4 v = *(const f32x4*)(p.x + ((b * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * (long)p.C + c);
+                if (n == 0) s0 = v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double d = (double)(v[e] - s0[e]); sd[e] += d; sq[e] += d * d; }
+                ++n;
+                x += nsub;
+                while (x >= p.W) { x -= p.W; if (++y >= p.H) { y = 0; ++b; } }
+            }
+        }
+        s_n[tid] = (double)n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double m = n ? sd[e] / (double)n : 0.0;
+            s_mean[tid][e] = (double)s0[e] + m;
+            s_m2[tid][e] = n ? sq[e] - sd[e] * m : 0.0;
+        }
+        __syncthreads();
+        if (sub == 0) {
+            double na = s_n[tid], mean[4], m2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { mean[e] = s_mean[tid][e]; m2[e] = s_m2[tid][e]; }
+            for (int k = 1; k < nsub; ++k) {
+                const int o = k * Qb + ql;
+                const double nb = s_n[o];
+                if (nb == 0.0) continue;
+                const double nn = na + nb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double d = s_mean[o][e] - mean[e];
+                    mean[e] += d * (nb / nn);
+                    m2[e] += s_m2[o][e] + d * d * (na * nb / nn);
+                }
+                na = nn;
+            }
+            double* o = p.part + (size_t)blockIdx.x * 3 * p.C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[c + e] = na; o[p.C + c + e] = mean[e]; o[2 * p.C + c + e] = m2[e]; }
+        }
+        __syncthreads();
+    }
+}
+// merge of the block partials; out = norm params [4][C]: mean, rsqrt(M2/N + 1e-8), -3e38, +3e38 (frame mode does not clamp).
+// launch: C/4 blocks of 256 threads = 4 channels x 64 lanes; a lane folds every 64th block, then a butterfly of Chan merges.
+__global__ __launch_bounds__(256) void chan_stat1_final_k(const double* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+    const int cl = threadIdx.x >> 6, kl = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + cl;
+    double na = 0.0, mean = 0.0, m2 = 0.0;
+    if (c < C)
+        for (int k = kl; k < nblk; k += 64) {
+            const double* o = part + (size_t)k * 3 * C;
+            const double nb = o[c];
+            if (nb == 0.0) continue;
+            const double nn = na + nb, d = o[C + c] - mean;
+            mean += d * (nb / nn);
+            m2 += o[2 * C + c] + d * d * (na * nb / nn);
+            na = nn;
+        }
+    for (int off = 32; off > 0; off >>= 1) {        // the wave IS the channel: xor butterfly, both partners compute the same merge
+        const double nb = __shfl_xor(na, off), mb = __shfl_xor(mean, off), qb = __shfl_xor(m2, off);
+        const double nn = na + nb;
+        if (nn > 0.0) {
+            const double d = mb - mean;
+            const double wb = nb / nn;
+            m2 += qb + d * d * (na * wb);
+            mean += d * wb;
+        }
+        na = nn;
+    }
+    if (kl != 0 || c >= C) return;
+    const float m = (float)mean;
+    const float var = (float)(m2 / na) + 1e-8f;
+    out[c] = m; out[C + c] = 1.0f / sqrtf(var); out[2 * C + c] = -3.0e38f; out[3 * C + c] = 3.0e38f;
+}
+
+// ---- FilterPredictor means without the convolution (frame mode) ---------------------------------------------------
+// FilterPredictor needs only mean_{HW} of down_sample(x) (test/style_network_frame.py:53-62).  The mean of a zero-padded
+// 3x3 convolution is linear in nine RECTANGLE SUMS of its input: tap (dy,dx) sees every pixel except the row / column
+// that falls outside:  mean_o = bias_o + (1/HW) sum_{c,tap} w[o][c][tap] * S[tap][c],
+//   S[(dy,dx)][c] = sum of x[y'][x'][c] over y' in [max(0,dy), H+min(0,dy)), x' likewise.
+// rect_sums_k: one block per channel quad of a [1,H,W,C] ring tensor -> S[9][C] (floats, accumulated in fp64).
+__global__ __launch_bounds__(256) void rect_sums_k(const float* __restrict__ x, int H, int W, int C, float* __restrict__ S) {
+    __shared__ double red[9][4][4];     // [tap][wave][e]
+    const int c = blockIdx.x * 4;
+    double acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.0;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int y = i / W, xx = i - y * W;
+        const f32x4 v = *(const f32x4*)(x + ((size_t)(y + 1) * (W + 2) + xx + 1) * C + c);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool in = (dy < 0 ? y < H - 1 : (dy > 0 ? y > 0 : true)) && (dx < 0 ? xx < W - 1 : (dx > 0 ? xx > 0 : true));
+            if (in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][e] += (double)v[e];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double a = acc[t][e];
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0) red[t][wave][e] = a;
+        }
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int t = threadIdx.x / 4, e = threadIdx.x & 3;
+        S[t * C + c + e] = (float)(red[t][0][e] + red[t][1][e] + red[t][2][e] + red[t][3][e]);
+    }
+}
+// out[o] = bias[o] + (1/HW) sum_{c,tap} w[o][c][tap] S[tap][c]   (w OIHW [32][C][3][3]); one block per output
+__global__ __launch_bounds__(256) void pred_mean_k(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ S, int C,
+                                                   double inv_hw, float* __restrict__ out) {
+    __shared__ double red[4];
+    const int o = blockIdx.x;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < C * 9; i += 256) {
+        const int c = i / 9, t = i - c * 9;
+        a += (double)w[((size_t)o * C + c) * 9 + t] * (double)S[t * C + c];
+    }
+    for (int k = 32; k > 0; k >>= 1) a += __shfl_xor(a, k);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[o] = (float)((red[0] + red[1] + red[2] + red[3]) * inv_hw + (double)bias[o]);
+}
+
 // ---- streaming statistics (compute() over groups of sampled frames) -------------------------------------------
 // Per channel the running (mean, M2 = centred sum of squares, min, max) of everything seen so far lives in
 // acc[4][C] doubles.  A group contributes its own two-pass partials — part0: sums, part1: squares about the group's

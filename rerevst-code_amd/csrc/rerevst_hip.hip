@@ -71,19 +71,18 @@ struct DecPlan {   // per-frame decoder activations for one (B, H, W) of the FRA
     float* pre = nullptr;   // [H][W][3] pre-clamp tap
 };
 
-// workspace of the preparation pass (compute_style) for one geometry; kept between calls in frame mode, where the
-// pass runs once per frame
+// workspace of the preparation pass (compute_style) for one geometry
 struct PrepPlan {
     int B = 0, hh = 0, ww = 0, sH = 0, sW = 0;
-    Tens cn, nxt, sn, t32, ts32, d32, u, xs[3], a[3], o[3];
-    float *cmean = nullptr, *smean = nullptr;
-    float* pre = nullptr;     // frame mode: [8hh][8ww][3] pre-clamp tap of the single-pass finish
+    Tens cn, nxt, t32, d32, u, xs[3], a[3], o[3];
+    float* cmean = nullptr;
 };
 
 struct StyleState {
     bool prepared = false, computed = false;
     float* blob = nullptr;           // RRV_STATE_FLOATS on device
     Tens map;                        // relu4_1 style map
+    float* smean = nullptr;          // [6][32]: mean_{HW} F{1,2}.down_sample(normalised style map) of Filter1..3 (FilterPredictor's style half, constant per style)
 };
 
 }  // namespace
@@ -123,6 +122,7 @@ struct rrv_ctx {
     double* stat_part = nullptr; float* stat_mean = nullptr;      // chan_stats scratch
     // streaming compute(): second partial buffer, two running accumulators [4][512] doubles, frame 0's filter residuals
     double* stat_part2 = nullptr; double* stat_acc = nullptr;
+    float *frame_S = nullptr, *frame_cmean = nullptr;      // frame mode: nine rectangle sums [9][512], predicted content means [2][32]
     Tens stream_u[3], stream_grp, stream_f0;
     size_t ws_cap = (size_t)64 << 30;          // preparation-pass workspace above which compute() streams groups of frames
     int last_groups = 0, last_group_size = 0; size_t last_ws_bytes = 0;
@@ -345,6 +345,8 @@ const ConvKey WINO_TABLE[] = {
     UW(E_LRELU | E_NORM1), UW(E_LRELU),
     // the same with the block's 1x1 shortcut fused in as a tenth position (per-frame path)
     UWS(E_LRELU | E_NORM1),
+    // frame mode: raw conv1 output (its statistics are per frame) + fused shortcut
+    UWS(E_LRELU),
 };
 
 int conv(rrv_handle h, const ConvCall& c) {
@@ -522,7 +524,7 @@ int pointwise(rrv_handle h, const Tens& x, Tens& y, const float* mean, const flo
 }
 
 // ---- folded KernelFilter weights for a state blob ------------------------------------------
-int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
+int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/, bool direct = true /* also the direct-form packs (compute()'s raw 32->512 conv) */) {
     char pre[64];
     snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
     const ConvW& wd = h->conv[std::string(pre) + ".down_sample.0"];
@@ -534,11 +536,11 @@ int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
     hipLaunchKernelGGL(fold_down_k, dim3((32 * 512 * 9 + 255) / 256), dim3(256), 0, h->stream, F1, (const float*)wd.raw,
                        (const float*)wd.bias, fd.raw, fd.bias, 512 * 9);
     HIPCHK(hipGetLastError());
-    RCHK(pack(h, fd));
+    if (direct) RCHK(pack(h, fd));
     RCHK(pack_wino(h, fd));          // 512->32 is one Winograd cout slab
     hipLaunchKernelGGL(fold_up_k, dim3((512 * 32 * 9 + 255) / 256), dim3(256), 0, h->stream, F2, (const float*)wu.raw, fu.raw, 512);
     HIPCHK(hipGetLastError());
-    RCHK(pack(h, fu));
+    if (direct) RCHK(pack(h, fu));
     RCHK(pack_wino(h, fu));          // 32 input channels = two 16-channel chunks per work item
     return RRV_OK;
 }
@@ -751,15 +753,11 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
 }
 
 // ---- preparation: Decoder.compute for one style ---------------------------------------------
-// frame_mode: the per-frame-statistics network of test/style_network_frame.py (use_Global=False) is this
-// same pass with B = 1 and no normalisation between the filters and the first AdaIN affine.
 void prep_free(rrv_handle h) {
     PrepPlan& P = h->prep;
-    for (Tens* t : {&P.cn, &P.nxt, &P.sn, &P.t32, &P.ts32, &P.d32, &P.u}) tfree(t);
+    for (Tens* t : {&P.cn, &P.nxt, &P.t32, &P.d32, &P.u}) tfree(t);
     for (int k = 0; k < 3; ++k) { tfree(&P.xs[k]); tfree(&P.a[k]); tfree(&P.o[k]); }
     if (P.cmean) (void)hipFree(P.cmean);
-    if (P.smean) (void)hipFree(P.smean);
-    if (P.pre) { if (h->last_pre == P.pre) h->last_pre = nullptr; (void)hipFree(P.pre); }
     P = PrepPlan{};
 }
 
@@ -769,12 +767,10 @@ int prep_plan(rrv_handle h, int B, int hh, int ww, int sH, int sW) {
     RCHK(sync_all(h));
     prep_free(h);
     P.B = B; P.hh = hh; P.ww = ww; P.sH = sH; P.sW = sW;
-    RCHK(dalloc(h, &P.cmean, 32)); RCHK(dalloc(h, &P.smean, 32));
+    RCHK(dalloc(h, &P.cmean, 64));
     RCHK(talloc(h, &P.cn, B, hh, ww, 512));
     RCHK(talloc(h, &P.nxt, B, hh, ww, 512));
-    RCHK(talloc(h, &P.sn, 1, sH, sW, 512));
     RCHK(talloc(h, &P.t32, B, hh, ww, 32));
-    RCHK(talloc(h, &P.ts32, 1, sH, sW, 32));
     RCHK(talloc(h, &P.d32, 1, hh, ww, 32));
     RCHK(talloc(h, &P.u, 1, hh, ww, 512));
     const int cout[3] = {256, 128, 64};
@@ -786,22 +782,20 @@ int prep_plan(rrv_handle h, int B, int hh, int ww, int sH, int sW) {
     return RRV_OK;
 }
 
-// keep_ws: leave the workspace allocated (frame mode); otherwise it is released at the end (several GB for a video's
-// sampled frames).  After the call P.o[2] holds the slice2 output before Decoder.norm[4] / AdaIN (stats in the blob).
-int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = false) {
+// The workspace is released at the end (several GB for a video's sampled frames).
+int compute_style(rrv_handle h, int sid, const Tens& content) {
     StyleState& S = h->styles[sid];
     float* st = S.blob;
     const int B = content.B, hh = content.H, ww = content.W;
     RCHK(prep_plan(h, B, hh, ww, S.map.H, S.map.W));
     PrepPlan& P = h->prep;
-    Tens &cn = P.cn, &nxt = P.nxt, &sn = P.sn, &t32 = P.t32, &ts32 = P.ts32, &d32 = P.d32, &u = P.u;
-    float *cmean = P.cmean, *smean = P.smean;
+    Tens &cn = P.cn, &nxt = P.nxt, &t32 = P.t32, &d32 = P.d32, &u = P.u;
+    float* cmean = P.cmean;
     auto body = [&]() -> int {
-        // norm[0].compute on the batch (style_network_global.py:396)
+        // norm[0].compute on the batch (style_network_global.py:396); the style half of the filter predictions
+        // (normalized_style :397 through F.down_sample, :161-172) was evaluated once in prepare_style (S.smean)
         RCHK(chan_stats(h, content, 1, st + SL.norm[N_DEC0]));
         RCHK(pointwise(h, content, cn, st + SL.norm[N_DEC0], st + SL.norm[N_DEC0] + 512, false, nullptr, 0, nullptr, nullptr));
-        // normalized_style = (style_map - mean)/std (:397)
-        RCHK(pointwise(h, S.map, sn, st + SL.sty[3], st + SL.sty[3] + 512, true, nullptr, 0, nullptr, nullptr));
         Tens* cur = &cn; Tens* other = &nxt;
         for (int f = 0; f < 3; ++f) {
             char pre[64];
@@ -810,10 +804,8 @@ int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = 
                 const ConvW* wp = &h->conv[std::string(pre) + (g ? ".F2" : ".F1") + ".down_sample.0"];
                 ConvCall c{cur, &t32, wp, hh, ww}; c.B = B; RCHK(conv(h, c));
                 RCHK(chan_stats(h, t32, 0, cmean));
-                ConvCall cs{&sn, &ts32, wp, sn.H, sn.W}; RCHK(conv(h, cs));
-                RCHK(chan_stats(h, ts32, 0, smean));
                 hipLaunchKernelGGL(fc_filter_k, dim3(4), dim3(256), 0, h->stream, (const float*)h->fc_w[2 * f + g],
-                                   (const float*)h->fc_b[2 * f + g], (const float*)cmean, (const float*)smean, st + SL.filt[2 * f + g]);
+                                   (const float*)h->fc_b[2 * f + g], (const float*)cmean, (const float*)(S.smean + (2 * f + g) * 32), st + SL.filt[2 * f + g]);
                 HIPCHK(hipGetLastError());
             }
             RCHK(fold_filters(h, st, f));
@@ -825,14 +817,9 @@ int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = 
             Tens* t = cur; cur = other; other = t;
         }
         h->active_src = -1;   // folded weights now belong to this style's blob; re-activate below
-        if (frame_mode) {   // style_network_frame.py AdaIN_filter: results * style_std + style_mean
-            hipLaunchKernelGGL(identity_norm_k, dim3(2), dim3(256), 0, h->stream, st + SL.norm[N_DEC1], 512);
-            HIPCHK(hipGetLastError());
-            RCHK(pointwise(h, *cur, *cur, nullptr, nullptr, false, nullptr, 0, st + SL.sty[3], st + SL.sty[3] + 512));
-        } else {            // AdaIN_compute(1) (style_network_global.py:428)
-            RCHK(chan_stats(h, *cur, 1, st + SL.norm[N_DEC1]));
-            RCHK(pointwise(h, *cur, *cur, st + SL.norm[N_DEC1], st + SL.norm[N_DEC1] + 512, false, nullptr, 0, st + SL.sty[3], st + SL.sty[3] + 512));
-        }
+        // AdaIN_compute(1) (style_network_global.py:428)
+        RCHK(chan_stats(h, *cur, 1, st + SL.norm[N_DEC1]));
+        RCHK(pointwise(h, *cur, *cur, st + SL.norm[N_DEC1], st + SL.norm[N_DEC1] + 512, false, nullptr, 0, st + SL.sty[3], st + SL.sty[3] + 512));
         struct Blk { const char* name; int cout, n1, n2, nada, sty; };
         const Blk blks[3] = {{"slice4", 256, N_S4N1, N_S4N2, N_DEC2, 2}, {"slice3", 128, N_S3N1, N_S3N2, N_DEC3, 1}, {"slice2", 64, N_S2N1, N_S2N2, N_DEC4, 0}};
         const Tens* in = cur;
@@ -859,12 +846,100 @@ int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = 
     };
     int rc = body();
     if (rc == RRV_OK && h->debug) rc = debug_verify(h, "Decoder.compute");
-    if (!frame_mode || rc != RRV_OK) {
-        (void)hipStreamSynchronize(h->stream);
-        prep_free(h);
-    }
+    (void)hipStreamSynchronize(h->stream);
+    prep_free(h);
     if (rc == RRV_OK) S.computed = true;
     return rc;
+}
+
+// ---- frame mode (Stylization(use_Global=False), test/style_network_frame.py) ----------------------------------------
+// Per-frame InstanceNorm statistics (:39-43: mean / biased variance over (H,W), no clamp) and per-frame filter prediction
+// (:53-62, :97-105).  One frame per call, so Q1's batch collapse does not arise and the fused per-frame kernels run
+// wherever no statistic separates producer and consumer: encoder -> [stats] -> normalise -> per filter {rectangle sums ->
+// predicted means -> FC -> fold -> 512->32 (LReLU) -> 32->512 + residual} (the last one also applies the AdaIN affine,
+// :326-339 ends with * style_std + style_mean and no norm) -> per block {conv1 behind the upsample with the fused
+// shortcut (raw) -> [stats] -> normalise -> conv2 (raw) -> [stats] -> normalise + shortcut -> [stats] -> normalise +
+// AdaIN} -> slice1.  [stats] = ONE read of the tensor (chan_stat1_k) + a merge; the filter predictors' conv + mean is
+// replaced by nine rectangle sums and a 64 x 4608 product (prep_kernels.h), their style half is cached per style.
+int chan_stats1(rrv_handle h, const Tens& t, float* out) {
+    const long npix = (long)t.B * t.H * t.W;
+    int nblk = (int)((npix + 255) / 256);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    const int ppb = (int)((npix + nblk - 1) / nblk);
+    if (t.C > 512) return fail(h, RRV_E_ARG, "chan_stats: more than 512 channels");
+    if (!h->stat_part) HIPCHK(hipMalloc((void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
+    StatP sp{t.p, t.B, t.H, t.W, t.C, nullptr, h->stat_part, 0, ppb};
+    RCHK(launch(h, "chan_stat1", 0, 4.0 * npix * t.C, [&] { hipLaunchKernelGGL(chan_stat1_k, dim3(nblk), dim3(256), 0, h->stream, sp); }));
+    return launch(h, "chan_stat1_final", 0, 0, [&] {
+        hipLaunchKernelGGL(chan_stat1_final_k, dim3((t.C + 3) / 4), dim3(256), 0, h->stream, (const double*)h->stat_part, nblk, t.C, out);
+    });
+}
+int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* d_out) {
+    StyleState& S = h->styles[0];
+    float* st = S.blob;
+    h->stream = h->streams[0];
+    RCHK(enc_plan(h, h->enc_frame[0], 1, H, W));
+    RCHK(dec_plan(h, h->dec[0], 1, H, W));
+    EncPlan& e = h->enc_frame[0];
+    DecPlan& d = h->dec[0];
+    if (!h->frame_S) { RCHK(dalloc(h, &h->frame_S, 9 * 512)); RCHK(dalloc(h, &h->frame_cmean, 64)); }
+    RCHK(run_encoder(h, e, d_img, 0, nullptr));
+    Tens& c41 = e.c41;
+    const int hh = c41.H, ww = c41.W;
+    // Decoder.norm[0] with this frame's statistics
+    RCHK(chan_stats1(h, c41, st + SL.norm[N_DEC0]));
+    RCHK(pointwise(h, c41, c41, st + SL.norm[N_DEC0], st + SL.norm[N_DEC0] + 512, false, nullptr, 0, nullptr, nullptr));
+    hipLaunchKernelGGL(identity_norm_k, dim3(2), dim3(256), 0, h->stream, st + SL.norm[N_DEC1], 512);
+    HIPCHK(hipGetLastError());
+    const Tens* cur = &c41;
+    Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
+    for (int f = 0; f < 3; ++f) {
+        RCHK(launch(h, "rect_sums", 0, 4.0 * hh * ww * 512, [&] {
+            hipLaunchKernelGGL(rect_sums_k, dim3(128), dim3(256), 0, h->stream, (const float*)cur->p, hh, ww, 512, h->frame_S);
+        }));
+        for (int g = 0; g < 2; ++g) {
+            char key[96];
+            snprintf(key, sizeof key, "Decoder.Filter%d.F%d.down_sample.0", f + 1, g + 1);
+            const ConvW& wp = h->conv[key];
+            RCHK(launch(h, "pred_mean", 2.0 * 32 * 4608, 0, [&] {
+                hipLaunchKernelGGL(pred_mean_k, dim3(32), dim3(256), 0, h->stream, (const float*)wp.raw, (const float*)wp.bias, (const float*)h->frame_S, 512,
+                                   1.0 / ((double)hh * ww), h->frame_cmean + 32 * g);
+            }));
+            hipLaunchKernelGGL(fc_filter_k, dim3(4), dim3(256), 0, h->stream, (const float*)h->fc_w[2 * f + g], (const float*)h->fc_b[2 * f + g],
+                               (const float*)(h->frame_cmean + 32 * g), (const float*)(S.smean + (2 * f + g) * 32), st + SL.filt[2 * f + g]);
+            HIPCHK(hipGetLastError());
+        }
+        RCHK(fold_filters(h, st, f, false));
+        ConvCall c{cur, &d.d, &h->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
+        ConvCall u{&d.d, fo[f], &h->fold_up[f], hh, ww};
+        u.epi = E_RES | (f == 2 ? E_NORM2 : 0); u.res = cur;
+        if (f == 2) { u.n2 = st + SL.norm[N_DEC1]; u.sty = st + SL.sty[3]; }     // identity norm, then * style_std + style_mean
+        RCHK(conv(h, u));
+        cur = fo[f];
+    }
+    h->active_src = -1;        // the folded filter weights are this frame's
+    struct Blk { const char* name; Tens *xs, *a, *o; int cout, n1, n2, nada, sty; };
+    const Blk blks[3] = {{"slice4", &d.xs4, &d.a4, &d.o4, 256, N_S4N1, N_S4N2, N_DEC2, 2}, {"slice3", &d.xs3, &d.a3, &d.o3, 128, N_S3N1, N_S3N2, N_DEC3, 1},
+                         {"slice2", &d.xs2, &d.a2, &d.o2, 64, N_S2N1, N_S2N2, N_DEC4, 0}};
+    const Tens* in = cur;
+    for (int k = 0; k < 3; ++k) {
+        const Blk& b = blks[k];
+        const std::string p = std::string("Decoder.") + b.name;
+        ConvCall c;
+        c = ConvCall{in, b.a, &h->conv[p + ".conv1"], b.a->H, b.a->W}; c.ups = true; c.epi = E_LRELU; c.sc_out = b.xs; RCHK(conv(h, c));
+        RCHK(chan_stats1(h, *b.a, st + SL.norm[b.n1]));
+        RCHK(pointwise(h, *b.a, *b.a, st + SL.norm[b.n1], st + SL.norm[b.n1] + b.cout, false, nullptr, 0, nullptr, nullptr));
+        c = ConvCall{b.a, b.o, &h->conv[p + ".conv2"], b.a->H, b.a->W}; c.epi = E_LRELU; RCHK(conv(h, c));
+        RCHK(chan_stats1(h, *b.o, st + SL.norm[b.n2]));
+        RCHK(pointwise(h, *b.o, *b.o, st + SL.norm[b.n2], st + SL.norm[b.n2] + b.cout, false, b.xs, 2, nullptr, nullptr));
+        RCHK(chan_stats1(h, *b.o, st + SL.norm[b.nada]));     // (a fused pointwise + statistics pass measured slower than the two kernels)
+        RCHK(pointwise(h, *b.o, *b.o, st + SL.norm[b.nada], st + SL.norm[b.nada] + b.cout, false, nullptr, 0, st + SL.sty[b.sty], st + SL.sty[b.sty] + b.cout));
+        in = b.o;
+    }
+    RCHK(run_last(h, d.o2, 1, H, W, d_out, d.pre, nullptr));
+    if (h->debug) RCHK(debug_verify(h, "transfer (frame mode)"));
+    return RRV_OK;
 }
 
 // ---- streaming preparation pass ------------------------------------------------------------------------------
@@ -877,8 +952,8 @@ int compute_style(rrv_handle h, int sid, const Tens& content, bool frame_mode = 
 // statistics already known, contributes its partial (chan_merge_k) and is dropped.  Workspace = one group, whatever B.
 size_t tens_bytes(int B, int H, int W, int C) { return ((size_t)B * (H + 2) * (W + 2) * C + (size_t)20 * (W + 2 + 20) * C) * sizeof(float); }
 size_t prep_bytes(int B, int hh, int ww, int sH, int sW) {      // what prep_plan allocates (+ the [B,hh,ww,512] content batch)
-    size_t n = 2 * tens_bytes(B, hh, ww, 512) + tens_bytes(1, sH, sW, 512) + tens_bytes(B, hh, ww, 32) + tens_bytes(1, sH, sW, 32) +
-               tens_bytes(1, hh, ww, 32) + tens_bytes(1, hh, ww, 512) + tens_bytes(B, hh, ww, 512);
+    (void)sH; (void)sW;
+    size_t n = 2 * tens_bytes(B, hh, ww, 512) + tens_bytes(B, hh, ww, 32) + tens_bytes(1, hh, ww, 32) + tens_bytes(1, hh, ww, 512) + tens_bytes(B, hh, ww, 512);
     const int cout[3] = {256, 128, 64};
     for (int k = 0, H = hh, W = ww; k < 3; ++k, H *= 2, W *= 2) n += tens_bytes(B, H, W, cout[k]) + 2 * tens_bytes(B, 2 * H, 2 * W, cout[k]);
     return n;
@@ -982,8 +1057,6 @@ int compute_style_streaming(rrv_handle h, int sid, int G) {
     for (int f = 0; f < 3; ++f) RCHK(talloc(h, &h->stream_u[f], 1, hh, ww, 512));
     const size_t img = h->stream_grp.img_floats();
     auto body = [&]() -> int {
-        // normalized_style (:397) for the filter predictions
-        RCHK(pointwise(h, S.map, P.sn, st + SL.sty[3], st + SL.sty[3] + 512, true, nullptr, 0, nullptr, nullptr));
         for (int stage = 0; stage < ST_COUNT; ++stage) {
             for (int g0 = 0; g0 < B; g0 += G) {
                 const int nb = B - g0 < G ? B - g0 : G;
@@ -996,14 +1069,10 @@ int compute_style_streaming(rrv_handle h, int sid, int G) {
                 RCHK(chan_stats_finish(h, 0, 512, (double)B * hh * ww, 1, st + SL.norm[N_DEC0]));
             } else if (stage >= ST_FILTER && stage < ST_FILTER + 3) {
                 const int f = stage - ST_FILTER;
-                char pre[64];
-                snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
                 for (int gi = 0; gi < 2; ++gi) {
                     RCHK(chan_stats_finish(h, gi, 32, (double)B * hh * ww, 0, P.cmean));
-                    ConvCall cs{&P.sn, &P.ts32, &h->conv[std::string(pre) + (gi ? ".F2" : ".F1") + ".down_sample.0"], P.sn.H, P.sn.W}; RCHK(conv(h, cs));
-                    RCHK(chan_stats(h, P.ts32, 0, P.smean));
                     hipLaunchKernelGGL(fc_filter_k, dim3(4), dim3(256), 0, h->stream, (const float*)h->fc_w[2 * f + gi], (const float*)h->fc_b[2 * f + gi],
-                                       (const float*)P.cmean, (const float*)P.smean, st + SL.filt[2 * f + gi]);
+                                       (const float*)P.cmean, (const float*)(S.smean + (2 * f + gi) * 32), st + SL.filt[2 * f + gi]);
                     HIPCHK(hipGetLastError());
                 }
                 RCHK(fold_filters(h, st, f));
@@ -1138,13 +1207,15 @@ int rrv_destroy(rrv_handle h) {
     for (float* p : h->patches) (void)hipFree(p);
     for (auto& f : h->features) if (f.p) (void)hipFree(f.p);
     free_plans(h);
-    for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); tfree(&s.map); }
+    for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); if (s.smean) (void)hipFree(s.smean); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->d_outf) (void)hipFree(h->d_outf);
     if (h->pend_u8) (void)hipFree(h->pend_u8);
     if (h->stat_part) (void)hipFree(h->stat_part);
     if (h->stat_mean) (void)hipFree(h->stat_mean);
     if (h->stat_part2) (void)hipFree(h->stat_part2);
+    if (h->frame_S) (void)hipFree(h->frame_S);
+    if (h->frame_cmean) (void)hipFree(h->frame_cmean);
     if (h->stat_acc) (void)hipFree(h->stat_acc);
     for (float* q : {h->first_w[0], h->first_w[1], h->first_b[0], h->first_b[1], h->first_wg}) if (q) (void)hipFree(q);
     for (auto& st : h->hstage) {
@@ -1269,6 +1340,24 @@ int rrv_prepare_style(rrv_handle h, const uint8_t* style, int Hs, int Ws, int si
     for (int k = 0; k < 4; ++k) RCHK(chan_stats(h, *taps[k], 2, S.blob + SL.sty[k]));
     RCHK(talloc(h, &S.map, 1, e.c41.H, e.c41.W, 512));
     HIPCHK(hipMemcpyAsync(S.map.p, e.c41.p, e.c41.img_floats() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    {   // FilterPredictor's style half (:161-172 with normalized_style :397): mean_{HW} F.down_sample((map - mean)/std), 6 x 32 values
+        if (!S.smean) RCHK(dalloc(h, &S.smean, 6 * 32));
+        Tens sn, ts32;
+        int rc = talloc(h, &sn, 1, S.map.H, S.map.W, 512);
+        if (rc == RRV_OK) rc = talloc(h, &ts32, 1, S.map.H, S.map.W, 32);
+        if (rc == RRV_OK) rc = pointwise(h, S.map, sn, S.blob + SL.sty[3], S.blob + SL.sty[3] + 512, true, nullptr, 0, nullptr, nullptr);
+        for (int f = 0; f < 3 && rc == RRV_OK; ++f)
+            for (int g = 0; g < 2 && rc == RRV_OK; ++g) {
+                char key[96];
+                snprintf(key, sizeof key, "Decoder.Filter%d.F%d.down_sample.0", f + 1, g + 1);
+                ConvCall cs{&sn, &ts32, &h->conv[key], sn.H, sn.W};
+                rc = conv(h, cs);
+                if (rc == RRV_OK) rc = chan_stats(h, ts32, 0, S.smean + (2 * f + g) * 32);
+            }
+        (void)hipStreamSynchronize(h->stream);
+        tfree(&sn); tfree(&ts32);
+        if (rc != RRV_OK) return rc;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->debug) RCHK(debug_verify(h, "prepare_style"));
     S.prepared = true; S.computed = false;
@@ -1678,7 +1767,7 @@ int rrv_release_features(rrv_handle h) {
 
 // Stylization(use_Global=False).transfer (test/framework.py:106-118 with test/style_network_frame.py):
 // per-frame InstanceNorm statistics and per-frame filter prediction.  Implemented as the preparation
-// pass on this one frame (B = 1, frame_mode) followed by the saved-state forward with that state.
+// frame_mode_forward above.
 int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame, int H, int W, float* out) {
     if (!h || !frame || !out) return RRV_E_ARG;
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
@@ -1690,24 +1779,13 @@ int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame, int H, int W, fl
     const size_t n = (size_t)H * W * 3;
     RCHK(ensure_u8(h, n));
     HIPCHK(hipMemcpyAsync(h->d_u8, frame, n, hipMemcpyHostToDevice, h->stream));
-    RCHK(enc_plan(h, h->enc_add, 1, H, W));
-    RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr));
-    Tens content = h->enc_add.c41;          // view: [1, H/8, W/8, 512] raw relu4_1 feature
-    // One pass: the preparation pass on this frame IS the frame-mode forward (per-frame statistics,
-    // test/style_network_frame.py:39-43) up to the last normalisation; finish with Decoder.norm[4] + AdaIN on its
-    // slice2 output and slice1.  (The saved-state forward would only repeat the same arithmetic.)
-    RCHK(compute_style(h, 0, content, true));
-    PrepPlan& P = h->prep;
-    const float* st = S.blob;
-    RCHK(pointwise(h, P.o[2], P.o[2], st + SL.norm[N_DEC4], st + SL.norm[N_DEC4] + 64, false, nullptr, 0, st + SL.sty[0], st + SL.sty[0] + 64));
     if (h->d_outf_cap < n) {
         if (h->d_outf) (void)hipFree(h->d_outf);
         h->d_outf = nullptr; h->d_outf_cap = 0;
         HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
         h->d_outf_cap = n;
     }
-    if (!P.pre) RCHK(dalloc(h, &P.pre, n, true));
-    RCHK(run_last(h, P.o[2], 1, H, W, h->d_outf, P.pre, nullptr));
+    RCHK(frame_mode_forward(h, h->d_u8, H, W, h->d_outf));
     HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
     HIPCHK(hipStreamSynchronize(h->streams[0]));
     return RRV_OK;
