@@ -1,9 +1,8 @@
-// conv_wino.h — 3x3 convolutions in a transform domain on the fp32 matrix cores: shared helpers, geometry and the
-// kernel conv_wino_k.  In the library conv_wino_k runs the UPSAMPLE-FUSED form (UPS = 1, 4 waves, two workgroups per
-// CU: ResidualBlock.conv1 behind the nearest-x2 upsample, test/style_network_global.py:100-103,116-118); the
-// F(2x2,3x3) layers run on conv_wino_split.h, which reuses everything here.  conv_wino_k's own F(2x2,3x3) forms
-// (UPS = 0; 4 waves, or 8 waves split by channel block) are the A/B references of tools/conv_microbench.hip and
-// tools/upw_check.hip.
+// conv_wino.h — 3x3 convolutions in a transform domain on the fp32 matrix cores: shared helpers, geometry (WinoGeo,
+// both forms) and the kernel conv_wino_k = the UPSAMPLE-FUSED form (UPS = 1, 4 waves, two workgroups per CU:
+// ResidualBlock.conv1 behind the nearest-x2 upsample, test/style_network_global.py:100-103,116-118).  The F(2x2,3x3)
+// layers run on conv_wino_split.h, which reuses everything here.  (The general kernel this one was specialised from —
+// with the superseded 4-wave / channel-split F(2x2,3x3) forms — lives in tools/conv_wino_ab.h for the microbenchmarks.)
 //
 // The 9-tap contraction becomes element-wise GEMMs over transform positions:
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A
@@ -180,9 +179,10 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-template <int EPI, int ABL = 0, int NW = 4, int UPS = 0, int SC = 0>
+template <int EPI, int ABL = 0, int NW = 4, int UPS = 1, int SC = 0>
 __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_wino_k(const ConvP p) {
-    static_assert(!SC || UPS, "the shortcut rides on the upsample-fused form");
+    static_assert(UPS == 1 && NW == 4, "library kernel: upsample-fused form, 4 waves (other forms: tools/conv_wino_ab.h)");
+    static_assert(!(EPI & E_POOL), "no pooling behind an upsample");
     using G = WinoGeo<NW, UPS, SC>;
     constexpr int NPU = G::NPU;
     constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, U_LDS = G::U_LDS, NT = G::NT, NB = G::NB, NP = G::NP, PW = G::PW, NPIECE = G::NPIECE;
@@ -191,8 +191,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
     const int lane = tid & 63, t = lane & 15, q = lane >> 4;
     const int tr = t >> 3, tc = t & 7;
-    const int tg = NW == 8 ? wave >> 1 : wave;          // tile group: output rows 4*tg .. 4*tg+3 of the workgroup tile
-    const int nb0 = NW == 8 ? wave & 1 : 0;             // first 16-cout block of this wave
+    const int tg = wave;                                // tile group: output rows 4*tg .. 4*tg+3 of the workgroup tile
     const int nchunks = p.Cin >> 4;      // even (Cin >= 64)
     const int n_ntiles = p.Cout >> 5;
 
@@ -238,16 +237,12 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     int asrc[G::RAW_IT];
 #pragma unroll
     for (int it = 0; it < G::RAW_IT; ++it) {
-        // UPS = 0, LDS pixel slot P: even halo columns first, then odd ones (HALF slots each), row-major inside;
-        // stored piece qq holds channels 4*(qq ^ ((hx>>1)&3)).. : conflict-free for the stride-2 patch reads.
-        // UPS = 1: row-major 10x10, piece qq holds channels 4*(qq ^ (hx&3)): conflict-free for the stride-1 reads
+        // LDS image: row-major 10x10 low-resolution halo, piece qq holds channels 4*(qq ^ (hx&3)): conflict-free for the stride-1 reads
         const int e = it * NT + tid;
         int P = e >> 2;
         const int qq = e & 3;
         if (P >= G::HALO * G::HALO) P = 0;
-        int hy, hx, swz;
-        if (UPS) { hy = P / 10; hx = P - hy * 10; swz = hx & 3; }
-        else { const int half = P >= G::HALF, rem = P - half * G::HALF; hy = rem / 9; hx = 2 * (rem - hy * 9) + half; swz = (hx >> 1) & 3; }
+        const int hy = P / 10, hx = P - hy * 10, swz = hx & 3;
         asrc[it] = ((hy * (p.Wi + 2) + hx) * p.Cin + 4 * (qq ^ swz)) * 4;
     }
     const int raw_last_num = ((G::RAW_IT - 1) * NT + wave * 64 < G::PIECES) ? 0x7fffffff : 0;
@@ -287,7 +282,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         }
     };
 
-    // LDS byte addresses: this lane's 4x4 raw patch (slot P, 16-byte piece q, XOR swizzle), relative to
+    // LDS byte addresses: this lane's 3x3 raw patch (16-byte piece q, XOR swizzle), relative to
     // the raw buffer; and its U fragment (row = pos*32 + nb*16 + t, (row>>2)&3 == (t>>2)&3)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     unsigned offD[NPIECE];   // index dx*PW + dy
@@ -295,33 +290,26 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     for (int dx = 0; dx < PW; ++dx)
 #pragma unroll
         for (int dy = 0; dy < PW; ++dy) {
-            if (UPS) {
-                const int hy = 2 * tg + tr + dy, hx = tc + dx;
-                offD[dx * PW + dy] = lds0 + (hy * 10 + hx) * 64 + ((q ^ (hx & 3)) << 4);
-            } else {
-                const int hy = 4 * tg + 2 * tr + dy, hx = 2 * tc + dx;
-                const int P = (hx & 1) * G::HALF + hy * 9 + (hx >> 1);
-                offD[dx * PW + dy] = lds0 + P * 64 + ((q ^ ((hx >> 1) & 3)) << 4);
-            }
+            const int hy = 2 * tg + tr + dy, hx = tc + dx;
+            offD[dx * PW + dy] = lds0 + (hy * 10 + hx) * 64 + ((q ^ (hx & 3)) << 4);
         }
-    const unsigned offU = lds0 + 2 * RAW_BYTES + nb0 * 1024 + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);
+    const unsigned offU = lds0 + 2 * RAW_BYTES + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);
     const unsigned offU1 = offU + U_LDS;
 
     f32x4 acc[NPU][NB];
     // transformed input B^T d B of the current / next chunk (ping-pong); V[r][k] lives in element k*PW + r: the
     // raw patch is read straight into the "next" array and both transform passes run in place.
-    // UPS = 0: B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]];  UPS = 1: B^T = [[0,1,0],[1,-1,0],[0,-1,1]]
+    // B^T = [[0,1,0],[1,-1,0],[0,-1,1]]
     f32x4 va[NPIECE], vb[NPIECE];
-    auto pass = [](f32x4& d0, f32x4& d1, f32x4& d2, f32x4& d3) {
-        const f32x4 a0 = d0, a1 = d1, a2 = d2, a3 = d3;
-        if (UPS) { d0 = a1; d1 = f4sub(a0, a1); d2 = f4sub(a2, a1); }
-        else { d0 = f4sub(a0, a2); d1 = f4add(a1, a2); d2 = f4sub(a2, a1); d3 = f4sub(a1, a3); }
+    auto pass = [](f32x4& d0, f32x4& d1, f32x4& d2) {
+        const f32x4 a0 = d0, a1 = d1, a2 = d2;
+        d0 = a1; d1 = f4sub(a0, a1); d2 = f4sub(a2, a1);
     };
     auto col_pass = [&](f32x4 (&d)[NPIECE], int dx) {   // d[dx*PW + dy] -> (B^T d)[r][dx] at d[dx*PW + r]
-        pass(d[dx * PW + 0], d[dx * PW + 1], d[dx * PW + 2], d[dx * PW + PW - 1]);
+        pass(d[dx * PW + 0], d[dx * PW + 1], d[dx * PW + 2]);
     };
     auto row_pass = [&](f32x4 (&d)[NPIECE], int r) {    // (B^T d)[r][.] -> V[r][k] at d[k*PW + r]
-        pass(d[0 * PW + r], d[1 * PW + r], d[2 * PW + r], d[(PW - 1) * PW + r]);
+        pass(d[0 * PW + r], d[1 * PW + r], d[2 * PW + r]);
     };
 
     // One chunk: MFMAs of chunk c with V(c) = vcur, while the raw patch of chunk c+1 is read and
@@ -366,14 +354,14 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         f32x4 u[4][NB];      // U fragments in flight, slot = pos & 3
         f32x4 (&d)[NPIECE] = vnext;   // raw patch of the next chunk, index dx*PW + dy; transformed in place
         u[0][0] = lds_rd128<0>(ub);                      // issue order = completion order: U(0) blocks, then U(1)
-        if constexpr (NB == 2) u[0][NB - 1] = lds_rd128<1024>(ub);
+        u[0][1] = lds_rd128<1024>(ub);
         u[1][0] = lds_rd128<2048>(ub);
-        if constexpr (NB == 2) u[1][NB - 1] = lds_rd128<2048 + 1024>(ub);
+        u[1][1] = lds_rd128<2048 + 1024>(ub);
         static_for([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if constexpr (i + 2 < NPU) {
                 u[(i + 2) & 3][0] = lds_rd128<(i + 2) * 2048>(ub);
-                if constexpr (NB == 2) u[(i + 2) & 3][NB - 1] = lds_rd128<(i + 2) * 2048 + 1024>(ub);
+                u[(i + 2) & 3][1] = lds_rd128<(i + 2) * 2048 + 1024>(ub);
             }
             static_for([&](auto kc) {
                 constexpr int pc = i * G::PPI + decltype(kc)::value;
@@ -381,19 +369,12 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
             }, std::make_integer_sequence<int, G::PPI>{});
             // U(i) is complete when at most younger(i) younger reads are outstanding; in-order return also
             // completes every patch piece issued before U(i): those of iterations <= i-3
-            constexpr int cdx = i - 3;      // UPS: col_iter(dx) = dx + 3 -> the patch column released in this iteration
-            if constexpr (UPS && NB == 2 && cdx >= 0 && cdx < PW) {   // one s_waitcnt for the column and the U fragments
+            constexpr int cdx = i - 3;      // col_iter(dx) = dx + 3 -> the patch column released in this iteration
+            static_assert(G::col_iter(0) == 3 && G::col_iter(PW - 1) == PW + 2, "column release schedule");
+            if constexpr (cdx >= 0 && cdx < PW) {   // one s_waitcnt for the column and the U fragments
                 asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(d[cdx * 3 + 0]), "+v"(d[cdx * 3 + 1]), "+v"(d[cdx * 3 + 2]), "+v"(u[i & 3][0]), "+v"(u[i & 3][1]) : "i"(G::younger(i)));
             } else {
-                static_for([&](auto xc) {
-                    constexpr int dx = decltype(xc)::value;
-                    if constexpr (G::col_iter(dx) == i) {
-                        if constexpr (PW == 4) lds_release4<G::younger(i)>(d[dx * 4 + 0], d[dx * 4 + 1], d[dx * 4 + 2], d[dx * 4 + 3]);
-                        else lds_release3<G::younger(i)>(d[dx * 3 + 0], d[dx * 3 + 1], d[dx * 3 + 2]);
-                    }
-                }, std::make_integer_sequence<int, PW>{});
-                if constexpr (NB == 2) lds_release2<G::younger(i)>(u[i & 3][0], u[i & 3][1]);
-                else lds_release1<G::younger(i)>(u[i & 3][0]);
+                lds_release2<G::younger(i)>(u[i & 3][0], u[i & 3][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
@@ -462,8 +443,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         // the next item's first tiles were requested by the last two chunks
         cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;
         // ---- output transform + fused epilogue (all in registers)
-        const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
-        float* out_b = p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
+        float* out_b = p.out + (size_t)e_b * (size_t)(p.H + 2) * (p.W + 2) * p.Cout;
         const float* res_b = nullptr;
         if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
         const int yb = e_y0 + 4 * tg + 2 * tr, xb = e_x0 + 2 * tc;
@@ -479,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
                         const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
                         resv[nb][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                         if (y < p.H && x < p.W)
-                            resv[nb][i][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + (nb0 + nb) * 16 + 4 * q);
+                            resv[nb][i][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + nb * 16 + 4 * q);
                     }
         }
         if constexpr (SC) {      // shortcut output: one low-resolution pixel per tile, no bias (conv_shortcut has none)
@@ -487,39 +467,25 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
             if (ly < p.Hi && lx < p.Wi) {
                 float* sc_b = p.sc_out + (size_t)e_b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cout + ((size_t)(ly + 1) * (p.Wi + 2) + lx + 1) * p.Cout;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) *(f32x4*)(sc_b + e_ntile * 32 + (nb0 + nb) * 16 + 4 * q) = acc[NP][nb];
+                for (int nb = 0; nb < NB; ++nb) *(f32x4*)(sc_b + e_ntile * 32 + nb * 16 + 4 * q) = acc[NP][nb];
             }
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const int co = e_ntile * 32 + (nb0 + nb) * 16 + 4 * q;
-            f32x4 Y[2][2];
-            if constexpr (UPS) {   // A^T = [[1,1,0],[1,0,1]]
-                f32x4 T[2][3];
+            const int co = e_ntile * 32 + nb * 16 + 4 * q;
+            f32x4 Y[2][2];      // A^T = [[1,1,0],[1,0,1]]
+            f32x4 T[2][3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    T[0][c] = acc[0 + c][nb] + acc[3 + c][nb];
-                    T[1][c] = acc[0 + c][nb] + acc[6 + c][nb];
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    Y[i][0] = T[i][0] + T[i][1];
-                    Y[i][1] = T[i][0] + T[i][2];
-                }
-            } else {               // A^T = [[1,1,1,0],[0,1,-1,-1]]
-                f32x4 T[2][4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    T[0][c] = acc[0 + c][nb] + acc[4 + c][nb] + acc[8 + c][nb];
-                    T[1][c] = acc[4 + c][nb] - acc[8 + c][nb] - acc[12 + c][nb];
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    Y[i][0] = T[i][0] + T[i][1] + T[i][2];
-                    Y[i][1] = T[i][1] - T[i][2] - T[i][3];
-                }
+            for (int c = 0; c < 3; ++c) {
+                T[0][c] = acc[0 + c][nb] + acc[3 + c][nb];
+                T[1][c] = acc[0 + c][nb] + acc[6 + c][nb];
             }
-            const char* pl = par + ((nb0 + nb) * 16 + 4 * q) * 4;      // this lane's 4 channels inside a 128-byte parameter row
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                Y[i][0] = T[i][0] + T[i][1];
+                Y[i][1] = T[i][0] + T[i][2];
+            }
+            const char* pl = par + (nb * 16 + 4 * q) * 4;      // this lane's 4 channels inside a 128-byte parameter row
             const f32x4 bias = *(const f32x4*)(pl);
             f32x4 m1, r1, lo1, hi1, m2, r2, lo2, hi2, smean, sstd;
             if (EPI & E_NORM1) {
@@ -531,37 +497,22 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
                 lo2 = *(const f32x4*)(pl + 896); hi2 = *(const f32x4*)(pl + 1024);
                 smean = *(const f32x4*)(pl + 1152); sstd = *(const f32x4*)(pl + 1280);
             }
-            f32x4 pooled;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int y = yb + i, x = xb + j;
-                    const bool valid = (y < p.H) && (x < p.W);
                     f32x4 o = e4add(Y[i][j], bias);
                     if (EPI & E_RELU) o = f4relu(o);
                     if (EPI & E_LRELU) o = f4lrelu(o);
                     if (EPI & E_NORM1) o = f4norm_clamp(o, m1, r1, lo1, hi1);
                     if (EPI & (E_RES | E_RES_UPS)) o = e4add(o, resv[nb][i][j]);
                     if (EPI & E_NORM2) o = e4fma(f4norm_clamp(o, m2, r2, lo2, hi2), sstd, smean);
-                    if (EPI & E_POOL) {
-                        if (i == 0 && j == 0) pooled = o;
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], o[e]);
-                        }
-                    } else if (valid) {
+                    if (y < p.H && x < p.W) {
                         if (ABL & 4) { if (o[0] == 123.456f) out_b[co] = o[0]; }
                         else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
                     }
                 }
-            if (EPI & E_POOL) {
-                const int y2 = yb >> 1, x2 = xb >> 1;
-                if (y2 < Ho && x2 < Wo) {
-                    if (ABL & 4) { if (pooled[0] == 123.456f) out_b[co] = pooled[0]; }
-                    else *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
-                }
-            }
         }
         tick(5);                              // epilogue issue
     }

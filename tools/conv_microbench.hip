@@ -6,7 +6,7 @@
 #include <vector>
 #include <math.h>
 #include "../rerevst-code_amd/csrc/conv_mfma.h"
-#include "../rerevst-code_amd/csrc/conv_wino.h"
+#include "conv_wino_ab.h"
 #include "../rerevst-code_amd/csrc/conv_wino_split.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -34,13 +34,13 @@ float run_wino(ConvP p, int iters, int xcd = 0) {
     p.tiles_y = (p.H + 15) / 16;
     int items = p.tiles_x * p.tiles_y * p.B * (p.Cout / 32);
     dim3 grid(items < 256 ? items : 256, 1);
-    CK(hipFuncSetAttribute((const void*)conv_wino_k<E_RELU, ABL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeo<NW, 0>::SMEM)));
+    CK(hipFuncSetAttribute((const void*)conv_wino_ab_k<E_RELU, ABL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeo<NW, 0>::SMEM)));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL, NW>), grid, dim3(NW * 64), (WinoGeo<NW, 0>::SMEM), 0, p);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_wino_ab_k<E_RELU, ABL, NW>), grid, dim3(NW * 64), (WinoGeo<NW, 0>::SMEM), 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_k<E_RELU, ABL, NW>), grid, dim3(NW * 64), (WinoGeo<NW, 0>::SMEM), 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_ab_k<E_RELU, ABL, NW>), grid, dim3(NW * 64), (WinoGeo<NW, 0>::SMEM), 0, p);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -139,10 +139,10 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
         dim3 grid(items < 256 ? items : 256, 1);
         std::vector<float> o4(out_f), o8(out_f);
         CK(hipMemset(out, 0, out_f * 4));
-        hipLaunchKernelGGL((conv_wino_k<E_RELU, 0, 4>), grid, dim3(256), (WinoGeo<4, 0>::SMEM), 0, q);
+        hipLaunchKernelGGL((conv_wino_ab_k<E_RELU, 0, 4>), grid, dim3(256), (WinoGeo<4, 0>::SMEM), 0, q);
         CK(hipMemcpy(o4.data(), out, out_f * 4, hipMemcpyDeviceToHost));
         CK(hipMemset(out, 0, out_f * 4));
-        hipLaunchKernelGGL((conv_wino_k<E_RELU, 0, 8>), grid, dim3(512), (WinoGeo<8, 0>::SMEM), 0, q);
+        hipLaunchKernelGGL((conv_wino_ab_k<E_RELU, 0, 8>), grid, dim3(512), (WinoGeo<8, 0>::SMEM), 0, q);
         CK(hipMemcpy(o8.data(), out, out_f * 4, hipMemcpyDeviceToHost));
         double md = 0; size_t bad = 0, first = 0;
         for (size_t i = 0; i < out_f; ++i) { double d = fabs((double)o4[i] - o8[i]); if (d > 1e-5) { if (!bad) first = i; ++bad; } if (d > md) md = d; }
@@ -155,8 +155,8 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
         ConvP q = p; q.dbg = dbg; q.xcd_slabs = 1; q.tiles_y = (q.H + 15) / 16;
         int items = q.tiles_x * q.tiles_y * q.B * (q.Cout / 32);
         dim3 grid(items < 256 ? items : 256, 1);
-        CK(hipFuncSetAttribute((const void*)conv_wino_k<E_RELU, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeo<4, 0>::SMEM)));
-        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((conv_wino_k<E_RELU, 16, 4>), grid, dim3(256), (WinoGeo<4, 0>::SMEM), 0, q);
+        CK(hipFuncSetAttribute((const void*)conv_wino_ab_k<E_RELU, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeo<4, 0>::SMEM)));
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((conv_wino_ab_k<E_RELU, 16, 4>), grid, dim3(256), (WinoGeo<4, 0>::SMEM), 0, q);
         CK(hipDeviceSynchronize());
         std::vector<long long> h((size_t)grid.x * 4 * 6);
         CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));

@@ -1,4 +1,4 @@
-// tools/upw_check.hip — conv_wino_k<.., UPS = 1> (nearest-x2 upsample + 3x3 conv) against a scalar CPU loop.
+// tools/upw_check.hip — conv_wino_ab_k<.., UPS = 1> (nearest-x2 upsample + 3x3 conv) against a scalar CPU loop.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/upw_check.hip -o tools/bin/upw_check
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -6,7 +6,7 @@
 #include <math.h>
 #include <vector>
 #include "../rerevst-code_amd/csrc/conv_mfma.h"
-#include "../rerevst-code_amd/csrc/conv_wino.h"
+#include "conv_wino_ab.h"
 #include "../rerevst-code_amd/csrc/conv_wino_split.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -49,8 +49,8 @@ int check(int B, int Hl, int Wl, int Cin, int Cout, int tap = -1) {
         CK(hipFuncSetAttribute((const void*)conv_wino_split_k<E_LRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES));
         hipLaunchKernelGGL((conv_wino_split_k<E_LRELU>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, p);
     } else {
-        CK(hipFuncSetAttribute((const void*)conv_wino_k<E_LRELU, 0, NW == 9 ? 8 : NW, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM));
-        hipLaunchKernelGGL((conv_wino_k<E_LRELU, 0, NW == 9 ? 8 : NW, UPS>), grid, dim3(NW * 64), Geo::SMEM, 0, p);
+        CK(hipFuncSetAttribute((const void*)conv_wino_ab_k<E_LRELU, 0, NW == 9 ? 8 : NW, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM));
+        hipLaunchKernelGGL((conv_wino_ab_k<E_LRELU, 0, NW == 9 ? 8 : NW, UPS>), grid, dim3(NW * 64), Geo::SMEM, 0, p);
     }
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(got.data(), out, out_f * 4, hipMemcpyDeviceToHost));
