@@ -297,11 +297,8 @@ def main():
     if NS:
         nW = len(feats)
         def step(i):
-            o = h_out[i & 1]
-            for j in range(B):
-                k = i * B + j
-                g = (first + k) % NF                     # global frame index -> the reference's weight ramp
-                model.transfer(feats[k % nW], video.ramp_weights(g, NF, NS), out=o[j])
+            ks = [i * B + j for j in range(B)]           # global frame index -> the reference's weight ramp
+            model.transfer_many([feats[k % nW] for k in ks], [video.ramp_weights((first + k) % NF, NF, NS) for k in ks], out=h_out[i & 1])
     else:
         n_batches = max(1, min(max(1, NF // B), args.steps))          # distinct batches kept resident in host memory
         my_ids = [(first + i) % NF for i in range(n_batches * B)]
@@ -362,7 +359,7 @@ def main():
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": what, "entry": ("rrv_transfer_features: relu4_1 feature in HBM -> float32 frame in %s host memory" if NS else
+               "config": {"workload": what, "entry": ("rrv_transfer_features_batch: relu4_1 features in HBM -> float32 frames in %s host memory" if NS else
                                                       "rrv_transfer_batch: uint8 frames in %s host memory -> float32 frames in the same (H2D + kernels + D2H)")
                                                % ("pageable" if args.pageable else "page-locked"),
                           "frames_per_step_per_gpu": B, "sub_batch": 1 if NS else 8, "batches_in_flight": args.pipeline,

@@ -135,6 +135,10 @@ int rrv_transfer_frames(rrv_handle h, const uint8_t* frames_bgr, int B, int H, i
 int rrv_generate_content_features(rrv_handle h, const uint8_t* frame_bgr, int H, int W, int* feature_id);
 int rrv_add_patch(rrv_handle h, int feature_id);
 int rrv_transfer_features(rrv_handle h, int feature_id, const float* style_weight, int n_styles, float* out_bgr);
+/* n cached features with one weight vector each (style_weight[n][n_styles], out_bgr[n][H][W][3]) in one call — what the
+ * reference driver's loop does frame by frame (test.py:127-131) — pipelined inside: consecutive frames alternate over
+ * two (stream, workspace, blended-state) sets and the D2H copy of one frame overlaps the next frame's kernels. */
+int rrv_transfer_features_batch(rrv_handle h, const int* feature_ids, const float* style_weight, int n, int n_styles, float* out_bgr);
 int rrv_release_features(rrv_handle h);
 
 /* Stylization(checkpoint, cuda, use_Global=False).transfer (test/framework.py:69-72,106-118 with

@@ -40,6 +40,7 @@ SYMBOLS = {
     "rrv_generate_content_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rrv_add_patch": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_transfer_features": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "rrv_transfer_features_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     "rrv_release_features": (C.c_int, [C.c_void_p]),
     "rrv_transfer_frame_mode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rrv_get_preclamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

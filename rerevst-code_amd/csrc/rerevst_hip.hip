@@ -105,11 +105,13 @@ struct rrv_ctx {
     float *last_w = nullptr, *last_b = nullptr;
     float* fc_w[6] = {nullptr}; float* fc_b[6] = {nullptr};
     float* zero_bias = nullptr;                // 512 zeros
-    // folded KernelFilter weights for the ACTIVE state
-    ConvW fold_down[3], fold_up[3];
+    // The state the per-frame path reads (blob layout) and the KernelFilter weights folded with its dynamic filters.
+    // Set 0 serves every single-state entry; the batched multi-style entry gives each in-flight frame (slot) its own set,
+    // since every frame there has its own blended state.  `cur` = the set the launch helpers use right now.
+    struct StateSet { float* active = nullptr; ConvW fold_down[3], fold_up[3]; } sets[RRV_MAX_SLOTS];
+    StateSet* cur = &sets[0];
     float* fold_tmp = nullptr;                 // OIHW scratch for folds (512*32*9 floats)
     StyleState styles[RRV_MAX_STYLES];
-    float* active = nullptr;                   // state the per-frame path reads (blob layout)
     int active_src = -1;                       // style id whose state is folded (-2: blend)
     EncPlan enc_frame[RRV_MAX_SLOTS], enc_add, enc_style;
     DecPlan dec[RRV_MAX_SLOTS];
@@ -529,8 +531,8 @@ int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/, bool direct = 
     snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
     const ConvW& wd = h->conv[std::string(pre) + ".down_sample.0"];
     const ConvW& wu = h->conv[std::string(pre) + ".upsample.0"];
-    ConvW& fd = h->fold_down[f];
-    ConvW& fu = h->fold_up[f];
+    ConvW& fd = h->cur->fold_down[f];
+    ConvW& fu = h->cur->fold_up[f];
     const float* F1 = blob + SL.filt[2 * f];
     const float* F2 = blob + SL.filt[2 * f + 1];
     hipLaunchKernelGGL(fold_down_k, dim3((32 * 512 * 9 + 255) / 256), dim3(256), 0, h->stream, F1, (const float*)wd.raw,
@@ -549,8 +551,8 @@ int activate_state(rrv_handle h, int style_id) {
     if (h->active_src == style_id) return RRV_OK;
     RCHK(sync_all(h));
     StyleState& s = h->styles[style_id];
-    HIPCHK(hipMemcpyAsync(h->active, s.blob, RRV_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
+    HIPCHK(hipMemcpyAsync(h->cur->active, s.blob, RRV_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->active_src = style_id;
     h->user_style = style_id;
@@ -656,7 +658,7 @@ struct Win { int y0, x0, y1, x1; };     // output window in pixels, tile aligned
 
 int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens& a, Tens& o, int n1, int n2, int nada, int sty,
                    const Win* wa = nullptr, const Win* wo = nullptr) {
-    const float* st = h->active;
+    const float* st = h->cur->active;
     const std::string p = std::string("Decoder.") + blk;
     ConvCall c;
     // conv1 behind the upsample and, in the same kernel, the 1x1 shortcut at the input resolution: up(conv1x1(x)) == conv1x1(up(x))
@@ -706,7 +708,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     RCHK(dec_plan(h, h->dec[slot], B, H, W));
     DecPlan& d = h->dec[slot];
     EncPlan& e = h->enc_frame[slot];
-    const float* st = h->active;
+    const float* st = h->cur->active;
     if (feat) {   // cached raw relu4_1 feature: Decoder.norm[0] (saved stats + clamp) as a pointwise step
         Tens src; src.p = const_cast<float*>(feat); src.B = 1; src.H = H / 8; src.W = W / 8; src.C = 512;
         const float* n0 = st + SL.norm[N_DEC0];
@@ -717,8 +719,8 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     const Tens* cur = &e.c41;
     Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
     for (int f = 0; f < 3; ++f) {
-        ConvCall c{cur, &d.d, &h->fold_down[f], cur->H, cur->W}; c.B = B; c.epi = E_LRELU; RCHK(conv(h, c));
-        ConvCall u{&d.d, fo[f], &h->fold_up[f], cur->H, cur->W}; u.B = B;
+        ConvCall c{cur, &d.d, &h->cur->fold_down[f], cur->H, cur->W}; c.B = B; c.epi = E_LRELU; RCHK(conv(h, c));
+        ConvCall u{&d.d, fo[f], &h->cur->fold_up[f], cur->H, cur->W}; u.B = B;
         u.epi = E_RES | (f == 2 ? E_NORM2 : 0); u.res = cur;
         if (f == 2) { u.n2 = st + SL.norm[N_DEC1]; u.sty = st + SL.sty[3]; }
         RCHK(conv(h, u));
@@ -811,8 +813,8 @@ int compute_style(rrv_handle h, int sid, const Tens& content) {
             RCHK(fold_filters(h, st, f));
             // KernelFilter.compute (:223-230): only frame 0 passes through apply_filter (Q1)
             Tens cur0 = *cur; cur0.B = 1;
-            ConvCall c{&cur0, &d32, &h->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
-            ConvCall cu{&d32, &u, &h->fold_up[f], hh, ww}; RCHK(conv(h, cu));
+            ConvCall c{&cur0, &d32, &h->cur->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
+            ConvCall cu{&d32, &u, &h->cur->fold_up[f], hh, ww}; RCHK(conv(h, cu));
             RCHK(pointwise(h, *cur, *other, nullptr, nullptr, false, &u, 1, nullptr, nullptr));
             Tens* t = cur; cur = other; other = t;
         }
@@ -911,8 +913,8 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
             HIPCHK(hipGetLastError());
         }
         RCHK(fold_filters(h, st, f, false));
-        ConvCall c{cur, &d.d, &h->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
-        ConvCall u{&d.d, fo[f], &h->fold_up[f], hh, ww};
+        ConvCall c{cur, &d.d, &h->cur->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
+        ConvCall u{&d.d, fo[f], &h->cur->fold_up[f], hh, ww};
         u.epi = E_RES | (f == 2 ? E_NORM2 : 0); u.res = cur;
         if (f == 2) { u.n2 = st + SL.norm[N_DEC1]; u.sty = st + SL.sty[3]; }     // identity norm, then * style_std + style_mean
         RCHK(conv(h, u));
@@ -1082,8 +1084,8 @@ int compute_style_streaming(rrv_handle h, int sid, int G) {
                 Tens cn0 = P.cn; cn0.B = 1;
                 RCHK(pointwise(h, h->stream_f0, cn0, st + SL.norm[N_DEC0], st + SL.norm[N_DEC0] + 512, false, nullptr, 0, nullptr, nullptr));
                 for (int f2 = 0; f2 < f; ++f2) RCHK(pointwise(h, cn0, cn0, nullptr, nullptr, false, &h->stream_u[f2], 1, nullptr, nullptr));
-                ConvCall c{&cn0, &P.d32, &h->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
-                ConvCall cu{&P.d32, &h->stream_u[f], &h->fold_up[f], hh, ww}; RCHK(conv(h, cu));
+                ConvCall c{&cn0, &P.d32, &h->cur->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
+                ConvCall cu{&P.d32, &h->stream_u[f], &h->cur->fold_up[f], hh, ww}; RCHK(conv(h, cu));
             } else if (stage == ST_NORM1) {
                 RCHK(chan_stats_finish(h, 0, 512, (double)B * hh * ww, 1, st + SL.norm[N_DEC1]));
             } else {
@@ -1308,15 +1310,17 @@ int rrv_finalize_weights(rrv_handle h) {
             RCHK(upload(h, q + ".FC.weight", &h->fc_w[2 * f + g], 1024 * 64));
             RCHK(upload(h, q + ".FC.bias", &h->fc_b[2 * f + g], 1024));
         }
-        ConvW& fd = h->fold_down[f];
-        fd.Cout = 32; fd.Cin = 512; fd.taps = 9; fd.BN = 32;
-        RCHK(dalloc(h, &fd.raw, 32 * 512 * 9)); RCHK(dalloc(h, &fd.pk, 32 * 512 * 9)); RCHK(dalloc(h, &fd.bias, 32));
-        ConvW& fu = h->fold_up[f];
-        fu.Cout = 512; fu.Cin = 32; fu.taps = 9; fu.BN = 128;
-        RCHK(dalloc(h, &fu.raw, 512 * 32 * 9)); RCHK(dalloc(h, &fu.pk, 512 * 32 * 9));
-        fu.bias = h->conv[std::string(pre) + ".upsample.0"].bias;
+        for (auto& set : h->sets) {
+            ConvW& fd = set.fold_down[f];
+            fd.Cout = 32; fd.Cin = 512; fd.taps = 9; fd.BN = 32;
+            RCHK(dalloc(h, &fd.raw, 32 * 512 * 9)); RCHK(dalloc(h, &fd.pk, 32 * 512 * 9)); RCHK(dalloc(h, &fd.bias, 32));
+            ConvW& fu = set.fold_up[f];
+            fu.Cout = 512; fu.Cin = 32; fu.taps = 9; fu.BN = 128;
+            RCHK(dalloc(h, &fu.raw, 512 * 32 * 9)); RCHK(dalloc(h, &fu.pk, 512 * 32 * 9));
+            fu.bias = h->conv[std::string(pre) + ".upsample.0"].bias;
+        }
     }
-    RCHK(dalloc(h, &h->active, RRV_STATE_FLOATS));
+    for (auto& set : h->sets) RCHK(dalloc(h, &set.active, RRV_STATE_FLOATS));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->hostw.clear();
     h->finalized = true;
@@ -1513,14 +1517,14 @@ int rrv_transfer_blend_device(rrv_handle h, const void* d_in, int H, int W, cons
     RCHK(sync_all(h));
     h->next_slot = 0;
     BlendP bp{};
-    bp.n = ns; bp.out = h->active; bp.count = RRV_STATE_FLOATS;
+    bp.n = ns; bp.out = h->cur->active; bp.count = RRV_STATE_FLOATS;
     for (int s = 0; s < ns; ++s) {
         if (!h->styles[s].computed) return fail(h, RRV_E_STATE, "blend: state not computed for every style");
         bp.st[s] = h->styles[s].blob; bp.w[s] = wts[s];
     }
     hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
     HIPCHK(hipGetLastError());
-    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
+    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f, false));
     h->active_src = -2;
     const int rc = transfer_device(h, (const uint8_t*)d_in, 1, H, W, (float*)d_out);
     h->next_slot = 0;
@@ -1732,14 +1736,14 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* wts, int ns
     const rrv_ctx::Feature& ft = h->features[feature_id];
     if ((ft.H % 8) || (ft.W % 8)) return fail(h, RRV_E_ARG, "transfer: feature of a frame whose sides are not multiples of 8");
     BlendP bp{};
-    bp.n = ns; bp.out = h->active; bp.count = RRV_STATE_FLOATS;
+    bp.n = ns; bp.out = h->cur->active; bp.count = RRV_STATE_FLOATS;
     for (int s = 0; s < ns; ++s) {
         if (!h->styles[s].computed) return fail(h, RRV_E_STATE, "blend: state not computed for every style");
         bp.st[s] = h->styles[s].blob; bp.w[s] = wts[s];
     }
     hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
     HIPCHK(hipGetLastError());
-    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->active, f));
+    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f, false));
     h->active_src = -2;
     const size_t n = (size_t)ft.H * ft.W * 3;
     if (h->d_outf_cap < n) {
@@ -1753,6 +1757,77 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* wts, int ns
     h->next_slot = 0;
     HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
     HIPCHK(hipStreamSynchronize(h->streams[0]));
+    return RRV_OK;
+}
+
+// n cached features, one weight vector each ([n][ns]), in ONE call: frame i runs on (stream, workspace, state set) i & 1,
+// its blend + filter folds + decoder overlap frame i-1's D2H copy (copy_out stream) and frame i+1's kernels.
+int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, int n, int ns, float* out) {
+    if (!h || !ids || !wts || !out || n < 1 || ns < 1 || ns > RRV_MAX_STYLES) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    for (int i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= (int)h->features.size() || !h->features[ids[i]].p) return fail(h, RRV_E_ARG, "transfer: unknown feature id");
+    for (int s = 0; s < ns; ++s)
+        if (!h->styles[s].computed) return fail(h, RRV_E_STATE, "blend: state not computed for every style");
+    const int H = h->features[ids[0]].H, W = h->features[ids[0]].W;
+    for (int i = 1; i < n; ++i)
+        if (h->features[ids[i]].H != H || h->features[ids[i]].W != W) return fail(h, RRV_E_ARG, "transfer: features of one call must share their size");
+    if ((H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: feature of a frame whose sides are not multiples of 8");
+    RCHK(sync_all(h));
+    const size_t npx = (size_t)H * W * 3;
+    const bool out_pin = is_pinned(out, (size_t)n * npx * sizeof(float));
+    const int nslots = (h->profiling || h->n_slots < 2 || n < 2) ? 1 : 2;
+    for (int i = 0; i < nslots; ++i) {
+        auto& st = h->hstage[i];
+        if (st.cap < npx) {
+            if (st.d_in) (void)hipFree(st.d_in);
+            if (st.d_out) (void)hipFree(st.d_out);
+            st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
+            HIPCHK(hipMalloc((void**)&st.d_in, npx));
+            HIPCHK(hipMalloc((void**)&st.d_out, npx * sizeof(float)));
+            st.cap = npx;
+        }
+        if (!out_pin && st.pcap < npx) {
+            if (st.pin_in) (void)hipHostFree(st.pin_in);
+            if (st.pin_out) (void)hipHostFree(st.pin_out);
+            st.pin_in = nullptr; st.pin_out = nullptr; st.pcap = 0;
+            HIPCHK(hipHostMalloc((void**)&st.pin_in, npx, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&st.pin_out, npx * sizeof(float), hipHostMallocDefault));
+            st.pcap = npx;
+        }
+    }
+    struct Restore { rrv_handle h; ~Restore() { h->cur = &h->sets[0]; h->stream = h->streams[0]; h->next_slot = 0; h->active_src = -2; } } restore{h};
+    auto drain = [&](int i) -> int {
+        auto& st = h->hstage[i % nslots];
+        HIPCHK(hipEventSynchronize(st.out_done));
+        if (!out_pin) host_copy(out + (size_t)i * npx, st.pin_out, npx * sizeof(float));
+        return RRV_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        const int slot = i % nslots;
+        auto& st = h->hstage[slot];
+        if (i >= nslots) {
+            if (!out_pin) RCHK(drain(i - nslots));
+            HIPCHK(hipStreamWaitEvent(h->streams[slot], st.out_done, 0));      // this slot's device output has left
+        }
+        h->stream = h->streams[slot];
+        h->cur = &h->sets[slot];
+        BlendP bp{};
+        bp.n = ns; bp.out = h->cur->active; bp.count = RRV_STATE_FLOATS;
+        for (int s = 0; s < ns; ++s) { bp.st[s] = h->styles[s].blob; bp.w[s] = wts[(size_t)i * ns + s]; }
+        hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
+        HIPCHK(hipGetLastError());
+        for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f, false));
+        h->active_src = -2;
+        h->next_slot = slot;
+        RCHK(transfer_device(h, nullptr, 1, H, W, st.d_out, h->features[ids[i]].p));
+        HIPCHK(hipEventRecord(st.k_done, h->streams[slot]));
+        HIPCHK(hipStreamWaitEvent(h->copy_out, st.k_done, 0));
+        HIPCHK(hipMemcpyAsync(out_pin ? (void*)(out + (size_t)i * npx) : (void*)st.pin_out, st.d_out, npx * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
+        HIPCHK(hipEventRecord(st.out_done, h->copy_out));
+    }
+    if (out_pin) HIPCHK(hipStreamSynchronize(h->copy_out));
+    else for (int i = (n - nslots < 0 ? 0 : n - nslots); i < n; ++i) RCHK(drain(i));
     return RRV_OK;
 }
 

@@ -279,5 +279,20 @@ class MultiStyleStylization(Stylization):
         self._chk(self._lib.rrv_transfer_features(self._h, cur_feature.id, w, len(style_weight), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def transfer_many(self, features, style_weights, out=None):
+        """`transfer` for a run of cached features, one weight vector each, pipelined inside the library
+        (rrv_transfer_features_batch).  Returns / fills a float32 [n][H][W][3] array."""
+        n = len(features)
+        H, W = features[0].shape[:2]
+        ns = len(style_weights[0])
+        if out is None:
+            out = np.empty((n, H, W, 3), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (n, H, W, 3) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape %r" % ((n, H, W, 3),))
+        ids = (C.c_int * n)(*[f.id for f in features])
+        w = (C.c_float * (n * ns))(*[float(v) for row in style_weights for v in row])
+        self._chk(self._lib.rrv_transfer_features_batch(self._h, ids, w, n, ns, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def release_features(self):
         self._chk(self._lib.rrv_release_features(self._h))

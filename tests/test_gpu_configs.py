@@ -170,3 +170,33 @@ def test_streaming_compute_b150_at_512_workspace_independent_of_b(pkg, weights):
     _, i40 = run(40, 6 * 2 ** 30)
     assert i40[1] == i150[1] and i40[2] == i150[2]        # same group size, same workspace: independent of B
     s.close()
+
+
+def test_multistyle_batched_transfer_equals_per_frame(pkg, weights, oracle):
+    """rrv_transfer_features_batch (frames alternating over two stream / workspace / blended-state sets, D2H overlapped)
+    == the same frames through rrv_transfer_features one by one, bit for bit; page-locked and pageable outputs; and a
+    plain transfer afterwards still uses the style's own state."""
+    V = importlib.import_module("rerevst-code_amd.video")
+    g = load_golden("multistyle_s4")
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7 + k) for k in range(4)]
+    frames = [oracle.reflect_pad(pkg.synth_frame(i, 64, 48, kind="smooth"), 192, 192) for i in range(7)]
+    s = pkg.MultiStyleStylization(weights, cuda=True, style_num=4)
+    s.prepare_style(styles)
+    feats = [s.generate_content_features(p) for p in frames]
+    s.clean()
+    for i in (0, 2):
+        s.add_patch(feats[i])
+    s.compute_norm()
+    wts = [V.ramp_weights(i, 7, 4) for i in range(7)]
+    wts[3] = [float(v) for v in g["weights"]]
+    single = np.stack([s.transfer(feats[i], wts[i]) for i in range(7)])
+    many = s.transfer_many(feats, wts)
+    np.testing.assert_array_equal(many, single)
+    pin = pkg.pinned_empty(single.shape, np.float32)
+    assert s.transfer_many(feats, wts, out=pin) is pin
+    np.testing.assert_array_equal(pin, single)
+    np.testing.assert_array_equal(s.transfer_many(feats[:1], wts[:1])[0], single[0])
+    one = pkg.Stylization.transfer(s, frames[1])                       # plain transfer: style 0's own state again
+    ref0 = pkg.Stylization.transfer(s, frames[1], style_weight=[1.0, 0.0, 0.0, 0.0])
+    assert np.abs(one - ref0).max() <= 1e-3
+    s.close()
