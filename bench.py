@@ -362,7 +362,7 @@ def main():
                "config": {"workload": what, "entry": ("rrv_transfer_features_batch: relu4_1 features in HBM -> float32 frames in %s host memory" if NS else
                                                       "rrv_transfer_batch: uint8 frames in %s host memory -> float32 frames in the same (H2D + kernels + D2H)")
                                                % ("pageable" if args.pageable else "page-locked"),
-                          "frames_per_step_per_gpu": B, "sub_batch": 1 if NS else 8, "batches_in_flight": args.pipeline,
+                          "frames_per_step_per_gpu": B, "sub_batch": 1 if NS else max(1, min(32, B, (8 * 640 * 640) // (P * P))), "batches_in_flight": args.pipeline,
                           "sampled_frames": len(video.sample_indices_multistyle(NF, 16) if NS else video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
                "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu,

@@ -574,8 +574,8 @@ int ensure_active(rrv_handle h) {
 }
 
 // ---- encoder ----------------------------------------------------------------------------
-int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {
-    if (e.B == B && e.H == H && e.W == W && e.c11.p) return RRV_OK;
+int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {      // grow-only in B: a plan made for more images serves fewer
+    if (e.B >= B && e.H == H && e.W == W && e.c11.p) return RRV_OK;
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "image too large ((H+2)*(W+2)*64 must be < 2^31)");
     e.B = B; e.H = H; e.W = W;
     const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
@@ -596,9 +596,10 @@ int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {
 // unpadded source frame behind a padded geometry (ReshapeTool on the device): pad on the way in, crop on the way out
 struct PadCrop { int src_H, src_W, top, left; };
 
-// nb > 0: encode only the first nb images of a plan made for more
-int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0, const PadCrop* pc = nullptr, int nb = 0) {
-    const int H = e.H, W = e.W, B = (nb > 0 && nb < e.B) ? nb : e.B;
+// nb: images to encode (plans are grow-only, so a plan may hold room for more)
+int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0, const PadCrop* pc, int nb) {
+    const int H = e.H, W = e.W, B = nb;
+    if (nb < 1 || nb > e.B) return fail(h, RRV_E_ARG, "run_encoder: batch does not fit the plan");
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "image too large ((H+2)*(W+2)*64 must be < 2^31)");
     FirstP fp{d_img, H, W, B, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16,
               which == 0 ? h->first_wg : nullptr, pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
@@ -633,7 +634,7 @@ int ensure_u8(rrv_handle h, size_t bytes) {
 
 // ---- per-frame decoder --------------------------------------------------------------------
 int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {
-    if (d.B == B && d.H == H && d.W == W && d.d.p) return RRV_OK;
+    if (d.B >= B && d.H == H && d.W == W && d.d.p) return RRV_OK;
     d.B = B; d.H = H; d.W = W;
     const int H8 = H / 8, W8 = W / 8, H4 = H / 4, W4 = W / 4, H2 = H / 2, W2 = W / 2;
     RCHK(talloc(h, &d.d, B, H8, W8, 32));
@@ -656,17 +657,17 @@ int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {
 
 struct Win { int y0, x0, y1, x1; };     // output window in pixels, tile aligned; y1 == 0: everything
 
-int resblock_frame(rrv_handle h, const char* blk, const Tens& in, Tens& xs, Tens& a, Tens& o, int n1, int n2, int nada, int sty,
+int resblock_frame(rrv_handle h, int B, const char* blk, const Tens& in, Tens& xs, Tens& a, Tens& o, int n1, int n2, int nada, int sty,
                    const Win* wa = nullptr, const Win* wo = nullptr) {
     const float* st = h->cur->active;
     const std::string p = std::string("Decoder.") + blk;
     ConvCall c;
     // conv1 behind the upsample and, in the same kernel, the 1x1 shortcut at the input resolution: up(conv1x1(x)) == conv1x1(up(x))
-    c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.B = in.B; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1];
+    c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.B = B; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1];
     c.sc_out = &xs;
     if (wa) { c.wy0 = wa->y0; c.wx0 = wa->x0; c.wy1 = wa->y1; c.wx1 = wa->x1; }
     RCHK(conv(h, c));
-    c = ConvCall{&a, &o, &h->conv[p + ".conv2"], a.H, a.W}; c.B = in.B;
+    c = ConvCall{&a, &o, &h->conv[p + ".conv2"], a.H, a.W}; c.B = B;
     c.epi = E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2; c.n1 = st + SL.norm[n2]; c.res = &xs; c.n2 = st + SL.norm[nada]; c.sty = st + SL.sty[sty];
     if (wo) { c.wy0 = wo->y0; c.wx0 = wo->x0; c.wy1 = wo->y1; c.wx1 = wo->x1; }
     RCHK(conv(h, c));
@@ -714,7 +715,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         const float* n0 = st + SL.norm[N_DEC0];
         RCHK(pointwise(h, src, e.c41, n0, n0 + 512, false, nullptr, 0, nullptr, nullptr, n0 + 1024, n0 + 1536));
     } else {
-        RCHK(run_encoder(h, e, d_in, 0, st + SL.norm[N_DEC0], pc));
+        RCHK(run_encoder(h, e, d_in, 0, st + SL.norm[N_DEC0], pc, B));
     }
     const Tens* cur = &e.c41;
     Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
@@ -726,8 +727,8 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         RCHK(conv(h, u));
         cur = fo[f];
     }
-    RCHK(resblock_frame(h, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2));
-    RCHK(resblock_frame(h, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1));
+    RCHK(resblock_frame(h, B, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2));
+    RCHK(resblock_frame(h, B, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1));
     // On-device crop: nothing outside the crop window is delivered, so the full-resolution layers only compute the
     // tiles the window (plus one halo pixel per 3x3 layer) needs; results inside the window are unchanged.  One level
     // down (320^2) the tile-rounded window already covers the frame for the reference's 64-pixel pad.
@@ -744,7 +745,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         wo = grow(crop, 1);        // slice2.conv2 output feeding them
         wa = grow(wo, 1);          // slice2.conv1 output (and, halved, the shortcut) feeding that
     }
-    RCHK(resblock_frame(h, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr));
+    RCHK(resblock_frame(h, B, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr));
     RCHK(run_last(h, d.o2, B, H, W, d_out, d.pre, pc, roi ? &wl : nullptr));
     if (h->caller_sync) {    // ... and whatever the caller queues next sees our output
         HIPCHK(hipEventRecord(h->slot_ev[slot], h->stream));
@@ -886,16 +887,18 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
     EncPlan& e = h->enc_frame[0];
     DecPlan& d = h->dec[0];
     if (!h->frame_S) { RCHK(dalloc(h, &h->frame_S, 9 * 512)); RCHK(dalloc(h, &h->frame_cmean, 64)); }
-    RCHK(run_encoder(h, e, d_img, 0, nullptr));
-    Tens& c41 = e.c41;
+    RCHK(run_encoder(h, e, d_img, 0, nullptr, nullptr, 1));
+    Tens c41 = e.c41; c41.B = 1;          // views of one image (plans are grow-only)
     const int hh = c41.H, ww = c41.W;
     // Decoder.norm[0] with this frame's statistics
     RCHK(chan_stats1(h, c41, st + SL.norm[N_DEC0]));
     RCHK(pointwise(h, c41, c41, st + SL.norm[N_DEC0], st + SL.norm[N_DEC0] + 512, false, nullptr, 0, nullptr, nullptr));
     hipLaunchKernelGGL(identity_norm_k, dim3(2), dim3(256), 0, h->stream, st + SL.norm[N_DEC1], 512);
     HIPCHK(hipGetLastError());
+    Tens f1 = d.f1, f2 = d.f2, f3 = d.f3, xs4 = d.xs4, a4 = d.a4, o4 = d.o4, xs3 = d.xs3, a3 = d.a3, o3 = d.o3, xs2 = d.xs2, a2 = d.a2, o2 = d.o2;
+    for (Tens* t : {&f1, &f2, &f3, &xs4, &a4, &o4, &xs3, &a3, &o3, &xs2, &a2, &o2}) t->B = 1;
     const Tens* cur = &c41;
-    Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
+    Tens* fo[3] = {&f1, &f2, &f3};
     for (int f = 0; f < 3; ++f) {
         RCHK(launch(h, "rect_sums", 0, 4.0 * hh * ww * 512, [&] {
             hipLaunchKernelGGL(rect_sums_k, dim3(128), dim3(256), 0, h->stream, (const float*)cur->p, hh, ww, 512, h->frame_S);
@@ -922,8 +925,8 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
     }
     h->active_src = -1;        // the folded filter weights are this frame's
     struct Blk { const char* name; Tens *xs, *a, *o; int cout, n1, n2, nada, sty; };
-    const Blk blks[3] = {{"slice4", &d.xs4, &d.a4, &d.o4, 256, N_S4N1, N_S4N2, N_DEC2, 2}, {"slice3", &d.xs3, &d.a3, &d.o3, 128, N_S3N1, N_S3N2, N_DEC3, 1},
-                         {"slice2", &d.xs2, &d.a2, &d.o2, 64, N_S2N1, N_S2N2, N_DEC4, 0}};
+    const Blk blks[3] = {{"slice4", &xs4, &a4, &o4, 256, N_S4N1, N_S4N2, N_DEC2, 2}, {"slice3", &xs3, &a3, &o3, 128, N_S3N1, N_S3N2, N_DEC3, 1},
+                         {"slice2", &xs2, &a2, &o2, 64, N_S2N1, N_S2N2, N_DEC4, 0}};
     const Tens* in = cur;
     for (int k = 0; k < 3; ++k) {
         const Blk& b = blks[k];
@@ -939,7 +942,7 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
         RCHK(pointwise(h, *b.o, *b.o, st + SL.norm[b.nada], st + SL.norm[b.nada] + b.cout, false, nullptr, 0, st + SL.sty[b.sty], st + SL.sty[b.sty] + b.cout));
         in = b.o;
     }
-    RCHK(run_last(h, d.o2, 1, H, W, d_out, d.pre, nullptr));
+    RCHK(run_last(h, o2, 1, H, W, d_out, d.pre, nullptr));
     if (h->debug) RCHK(debug_verify(h, "transfer (frame mode)"));
     return RRV_OK;
 }
@@ -1338,7 +1341,7 @@ int rrv_prepare_style(rrv_handle h, const uint8_t* style, int Hs, int Ws, int si
     HIPCHK(hipMemcpyAsync(h->d_u8, style, (size_t)Hs * Ws * 3, hipMemcpyHostToDevice, h->stream));
     RCHK(enc_plan(h, h->enc_style, 1, Hs, Ws));
     EncPlan& e = h->enc_style;
-    RCHK(run_encoder(h, e, h->d_u8, 1, nullptr));
+    RCHK(run_encoder(h, e, h->d_u8, 1, nullptr, nullptr, 1));
     // cal_mean_std at relu1_1..relu4_1 (style_network_global.py:304-331)
     const Tens* taps[4] = {&e.c11, &e.c21, &e.c31, &e.c41};
     for (int k = 0; k < 4; ++k) RCHK(chan_stats(h, *taps[k], 2, S.blob + SL.sty[k]));
@@ -1558,8 +1561,14 @@ static int host_roundtrip(rrv_handle h, const uint8_t* frames, int B, int H, int
 // sub-batch k+1.. (copy_in stream), the kernels of k and k+1 (the two compute streams), the D2H copy of k-1 (copy_out
 // stream); events order a set's H2D -> kernels -> D2H and its re-use four sub-batches later.  With pageable caller
 // arrays the host additionally copies into / out of the pinned staging buffers while all of that runs.
-constexpr int HOST_SUB = 8;
+constexpr long HOST_SUB_PIXELS = 8L * 640 * 640;      // pixels per sub-batch: 8 frames at the 512x512 configuration's padded size
 constexpr int HOST_SETS = 4;
+static int host_sub(int B, int H, int W) {              // frames per sub-batch: small frames are grouped, large ones split finer
+    long s = HOST_SUB_PIXELS / ((long)H * W);
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return B < s ? B : (int)s;
+}
 // copies between the caller's pageable arrays and the pinned staging buffers: first-touch page faults of a fresh
 // output array make a single thread slower than the GPU, so large copies are split over a few threads
 static void host_copy(void* dst, const void* src, size_t bytes) {
@@ -1590,7 +1599,7 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
     if (!h || !frames || !out || B < 1) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     const size_t fb = (size_t)H * W * 3;
-    const int sub = B < HOST_SUB ? B : HOST_SUB;
+    const int sub = pad_on_device ? host_sub(B, (H + 128 + 63) / 64 * 64, (W + 128 + 63) / 64 * 64) : host_sub(B, H, W);
     {   // refuse oversized frames before any staging buffer is sized for them
         const double ph = pad_on_device ? (double)((H + 128 + 63) / 64 * 64) : (double)H, pw = pad_on_device ? (double)((W + 128 + 63) / 64 * 64) : (double)W;
         if (H < 1 || W < 1 || (ph + 2) * (pw + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
@@ -1699,7 +1708,7 @@ int rrv_generate_content_features(rrv_handle h, const uint8_t* frame, int H, int
     RCHK(ensure_u8(h, (size_t)H * W * 3));
     HIPCHK(hipMemcpyAsync(h->d_u8, frame, (size_t)H * W * 3, hipMemcpyHostToDevice, h->stream));
     RCHK(enc_plan(h, h->enc_add, 1, H, W));
-    RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr));
+    RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr, nullptr, 1));
     const Tens& f = h->enc_add.c41;
     rrv_ctx::Feature ft{nullptr, H, W};
     const size_t slack = (size_t)20 * (f.W + 2 + 20) * 512;      // same slack as talloc: tile-overrun reads stay inside
