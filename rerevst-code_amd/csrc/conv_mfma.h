@@ -63,6 +63,8 @@ struct ConvP {
     float* sc_out;     // conv_wino_k<.., UPS = 1, SC = 1>: low-resolution output of the fused 1x1 shortcut [B,Hi,Wi,Cout] (ring layout)
     int ty0, tx0;      // transform-domain kernels: first tile row / column of the output window (tiles_x, tiles_y count its tiles)
     long long* dbg;    // microbench only (ABL & 16): per-phase cycle counters
+    int cstride;       // conv_wino_split_k, split K: channels per pixel of the input tensor (Cin = the slice one "cout slab" contracts); 0: = Cin
+    int cin_slab_step; // split K: slab s contracts input channels [s * cin_slab_step, + Cin) and writes output channels [32 s, 32 s + 32) — its partial sum
 };
 
 template <int BN>

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     const int half = wave & 1;                   // transform rows {0,1} / {3,2}; finishes output row `half` of each tile
     const float sgn = half ? -1.f : 1.f;
     const int nchunks = p.Cin >> 4;              // even
+    const int cs = p.cstride ? p.cstride : p.Cin;    // channels per pixel in memory (split K: the launch contracts a slice of them)
     const int n_ntiles = p.Cout >> 5;
 
     // ---- work items: identical walk to conv_wino_k (XCD-aware, incremental, scalar)
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         return r;
     };
     auto in_of = [&](const Item& a) {
-        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)(((a.ty + p.ty0) * 16) * (p.Wi + 2) + (a.tx + p.tx0) * 16) * p.Cin;
+        return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * cs + (size_t)(((a.ty + p.ty0) * 16) * (p.Wi + 2) + (a.tx + p.tx0) * 16) * cs +
+               (size_t)a.nt * p.cin_slab_step;
     };
     auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (16 * 32 * 16); };
     int asrc[G::RAW_IT];
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         if (P >= 324) P = 0;
         const int hf = P >= G::HALF, rem = P - hf * G::HALF;
         const int hy = rem / 9, hx = 2 * (rem - hy * 9) + hf;
-        asrc[it] = ((hy * (p.Wi + 2) + hx) * p.Cin + 4 * (qq ^ ((hx >> 1) & 3))) * 4;
+        asrc[it] = ((hy * (p.Wi + 2) + hx) * cs + 4 * (qq ^ ((hx >> 1) & 3))) * 4;
     }
     const int raw_last_num = ((G::RAW_IT - 1) * NT + wave * 64 < G::PIECES) ? 0x7fffffff : 0;
     bool have = cur.b < p.B, have_nxt = false;

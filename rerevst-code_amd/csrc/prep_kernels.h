@@ -226,37 +226,33 @@ __global__ __launch_bounds__(256) void chan_final_k(const double* __restrict__ p
 // (inside the data's range, so nothing cancels), turns them into (n, mean, M2) and the block merges its threads with the
 // pairwise update of Chan et al.; per block [n | mean | M2] x C doubles go to `part` ([nblk][3][C]).
 __global__ __launch_bounds__(256) void chan_stat1_k(const StatP p) {
+    // a block walks whole image rows (blockIdx.x, += gridDim.x): inside a row a thread's pixels are a constant stride
+    // apart, so the loads are independent of the accumulation and of each other (the compiler keeps several in flight)
     __shared__ double s_n[256], s_mean[256][4], s_m2[256][4];
     const int tid = threadIdx.x;
     const int CQ = p.C >> 2;
     const int Qb = CQ < 64 ? CQ : 64;
     const int nsub = 256 / Qb;
     const int ql = tid % Qb, sub = tid / Qb;
-    const long npix = (long)p.B * p.H * p.W;
-    const long p0 = (long)blockIdx.x * p.pix_per_blk;
-    long p1 = p0 + p.pix_per_blk;
-    if (p1 > npix) p1 = npix;
+    const int nrows = p.B * p.H;
     for (int cg = 0; cg < CQ; cg += Qb) {
         const int c = 4 * (cg + ql);
         double sd[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
         long n = 0;
-        if (sub < nsub) {
-            long q = p0 + sub;
-            int x = (int)(q % p.W);
-            long r = q / p.W;
-            int y = (int)(r % p.H);
-            long b = r / p.H;
-            for (; q < p1; q += nsub) {
-                const f32x4 v = *(const f32x4*)(p.x + ((b * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * (long)p.C + c);
-                if (n == 0) s0 = v;
+        if (sub < nsub)
+            for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+                const int b = r / p.H, y = r - b * p.H;
+                const float* row = p.x + (((long)b * (p.H + 2) + y + 1) * (p.W + 2) + 1) * (long)p.C + c;
+                if (n == 0 && sub < p.W) s0 = *(const f32x4*)(row + (long)sub * p.C);
+#pragma unroll 4
+                for (int x = sub; x < p.W; x += nsub) {
+                    const f32x4 v = *(const f32x4*)(row + (long)x * p.C);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const double d = (double)(v[e] - s0[e]); sd[e] += d; sq[e] += d * d; }
-                ++n;
-                x += nsub;
-                while (x >= p.W) { x -= p.W; if (++y >= p.H) { y = 0; ++b; } }
+                    for (int e = 0; e < 4; ++e) { const double d = (double)(v[e] - s0[e]); sd[e] += d; sq[e] += d * d; }
+                    ++n;
+                }
             }
-        }
         s_n[tid] = (double)n;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -329,6 +325,7 @@ __global__ __launch_bounds__(256) void chan_stat1_final_k(const double* __restri
 //   S[(dy,dx)][c] = sum of x[y'][x'][c] over y' in [max(0,dy), H+min(0,dy)), x' likewise.
 // rect_sums_k: one block per channel quad of a [1,H,W,C] ring tensor -> S[9][C] (floats, accumulated in fp64).
 __global__ __launch_bounds__(256) void rect_sums_k(const float* __restrict__ x, int H, int W, int C, float* __restrict__ S) {
+    // grid (C/4, NY): block (q, j) sums every NY-th 256-pixel slice of channel quad q into the partial S[j][9][C]
     __shared__ double red[9][4][4];     // [tap][wave][e]
     const int c = blockIdx.x * 4;
     double acc[9][4];
@@ -336,7 +333,8 @@ __global__ __launch_bounds__(256) void rect_sums_k(const float* __restrict__ x, 
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = 0.0;
-    for (int i = threadIdx.x; i < H * W; i += 256) {
+#pragma unroll 4
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < H * W; i += 256 * gridDim.y) {
         const int y = i / W, xx = i - y * W;
         const f32x4 v = *(const f32x4*)(x + ((size_t)(y + 1) * (W + 2) + xx + 1) * C + c);
 #pragma unroll
@@ -361,18 +359,20 @@ __global__ __launch_bounds__(256) void rect_sums_k(const float* __restrict__ x, 
     __syncthreads();
     if (threadIdx.x < 36) {
         const int t = threadIdx.x / 4, e = threadIdx.x & 3;
-        S[t * C + c + e] = (float)(red[t][0][e] + red[t][1][e] + red[t][2][e] + red[t][3][e]);
+        S[((size_t)blockIdx.y * 9 + t) * C + c + e] = (float)(red[t][0][e] + red[t][1][e] + red[t][2][e] + red[t][3][e]);
     }
 }
 // out[o] = bias[o] + (1/HW) sum_{c,tap} w[o][c][tap] S[tap][c]   (w OIHW [32][C][3][3]); one block per output
-__global__ __launch_bounds__(256) void pred_mean_k(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ S, int C,
+__global__ __launch_bounds__(256) void pred_mean_k(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ S, int nparts, int C,
                                                    double inv_hw, float* __restrict__ out) {
     __shared__ double red[4];
     const int o = blockIdx.x;
     double a = 0.0;
     for (int i = threadIdx.x; i < C * 9; i += 256) {
         const int c = i / 9, t = i - c * 9;
-        a += (double)w[((size_t)o * C + c) * 9 + t] * (double)S[t * C + c];
+        float sv = S[t * C + c];
+        for (int j = 1; j < nparts; ++j) sv += S[((size_t)j * 9 + t) * C + c];
+        a += (double)w[((size_t)o * C + c) * 9 + t] * (double)sv;
     }
     for (int k = 32; k > 0; k >>= 1) a += __shfl_xor(a, k);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
@@ -445,30 +445,59 @@ struct PointP {
     int Hr, Wr;
     const float* smean; const float* sstd;   // affine after
     const float* lo; const float* hi;        // clamp of the normalised value (saved-stat forward), may be null
+    int segs;                                // blocks per image row (small tensors still fill the chip)
 };
-__global__ void pointwise_k(const PointP p) {
-    const long total = (long)p.B * p.H * p.W * (p.C >> 2);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % (p.C >> 2)) * 4;
-        long r = i / (p.C >> 2);
-        const int x = (int)(r % p.W); r /= p.W;
-        const int y = (int)(r % p.H);
-        const long b = r / p.H;
-        const long idx = ((b * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * (long)p.C + c4;
-        float4 v = *(const float4*)(p.x + idx);
-        float* pv = &v.x;
+__global__ __launch_bounds__(256) void pointwise_k(const PointP p) {
+    // Blocks walk (image row, row segment) pairs; 256 is a multiple of C/4, so a thread keeps ONE channel quad: its
+    // per-channel parameters are loaded once, and inside a row its pixels are a constant stride apart.
+    const int CQ = p.C >> 2;
+    const int nrows = p.B * p.H;
+    const int sg = blockIdx.x % p.segs, rstep = gridDim.x / p.segs;
+    const int t0 = sg * 256 + threadIdx.x;
+    const int c4 = (t0 % CQ) * 4, x0 = t0 / CQ, xstep = p.segs * 256 / CQ;
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, scale = {1.f, 1.f, 1.f, 1.f}, lo, hi, smean, sstd;
+    if (p.mean) { mean = *(const f32x4*)(p.mean + c4); scale = *(const f32x4*)(p.scale + c4); }
+    if (p.lo) { lo = *(const f32x4*)(p.lo + c4); hi = *(const f32x4*)(p.hi + c4); }
+    if (p.smean) { smean = *(const f32x4*)(p.smean + c4); sstd = *(const f32x4*)(p.sstd + c4); }
+    for (int r = blockIdx.x / p.segs; r < nrows; r += rstep) {
+        const int b = r / p.H, y = r - b * p.H;
+        const long row = (((long)b * (p.H + 2) + y + 1) * (p.W + 2) + 1) * (long)p.C + c4;
+        const long rrow = (p.res_mode == 1 ? ((long)(y + 1) * (p.Wr + 2) + 1) * (long)p.C
+                         : p.res_mode == 2 ? (((long)b * (p.Hr + 2) + (y >> 1) + 1) * (p.Wr + 2) + 1) * (long)p.C : 0) + c4;
+#pragma unroll 2
+        for (int x = x0; x < p.W; x += xstep) {
+            const long idx = row + (long)x * p.C;
+            f32x4 v = *(const f32x4*)(p.x + idx);
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (p.res_mode == 1) rv = *(const f32x4*)(p.res + rrow + (long)x * p.C);
+            if (p.res_mode == 2) rv = *(const f32x4*)(p.res + rrow + (long)(x >> 1) * p.C);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = pv[e];
-            if (p.mean) t = p.div ? (t - p.mean[c4 + e]) / p.scale[c4 + e] : (t - p.mean[c4 + e]) * p.scale[c4 + e];
-            if (p.lo) t = fminf(p.hi[c4 + e], fmaxf(p.lo[c4 + e], t));
-            if (p.res_mode == 1) t += p.res[((long)(y + 1) * (p.Wr + 2) + x + 1) * p.C + c4 + e];
-            if (p.res_mode == 2)
-                t += p.res[((b * (p.Hr + 2) + (y >> 1) + 1) * (p.Wr + 2) + (x >> 1) + 1) * (long)p.C + c4 + e];
-            if (p.smean) t = t * p.sstd[c4 + e] + p.smean[c4 + e];
-            pv[e] = t;
+            for (int e = 0; e < 4; ++e) {
+                float tv = v[e];
+                if (p.mean) tv = p.div ? (tv - mean[e]) / scale[e] : (tv - mean[e]) * scale[e];
+                if (p.lo) tv = fminf(hi[e], fmaxf(lo[e], tv));
+                if (p.res_mode) tv += rv[e];
+                if (p.smean) tv = tv * sstd[e] + smean[e];
+                v[e] = tv;
+            }
+            *(f32x4*)(p.y + idx) = v;
         }
-        *(float4*)(p.y + idx) = v;
+    }
+}
+
+// split-K finish of the 512->32 KernelFilter convolution: part holds `split` partial sums per pixel as channels
+// [32 s, 32 s + 32) of a [.., 32 * split] ring-layout tensor; out[c] = LeakyReLU(sum_s part[32 s + c]) over every pixel
+// slot of the buffers (the ring is zero in every part and LeakyReLU(0) = 0).
+__global__ void sum_parts_lrelu_k(const float* __restrict__ part, float* __restrict__ out, int split, long npix) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix * 8; i += (long)gridDim.x * blockDim.x) {
+        const long px = i >> 3;
+        const int c4 = (int)(i & 7) * 4;
+        const float* src = part + px * 32 * split + c4;
+        f32x4 v = *(const f32x4*)src;
+        for (int k = 1; k < split; ++k) v += *(const f32x4*)(src + 32 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * 0.2f;
+        *(f32x4*)(out + px * 32 + c4) = v;
     }
 }
 

@@ -68,6 +68,7 @@ struct EncPlan {   // encoder activations for one (B, H, W)
 struct DecPlan {   // per-frame decoder activations for one (B, H, W) of the FRAME batch
     int B = 0, H = 0, W = 0;
     Tens d, f1, f2, f3, xs4, a4, o4, xs3, a3, o3, xs2, a2, o2;
+    Tens dpart;             // [.., 32 * split]: partial sums of the split-K 512->32 KernelFilter convolution (allocated on first use)
     float* pre = nullptr;   // [H][W][3] pre-clamp tap
 };
 
@@ -299,6 +300,9 @@ struct ConvCall {
     int wy0 = 0, wx0 = 0, wy1 = 0, wx1 = 0;   // transform-domain kernels: compute only output rows [wy0,wy1) x columns [wx0,wx1) (multiples of 16; all 0 = everything)
     const float* n1 = nullptr; const Tens* res = nullptr; const float* n2 = nullptr; const float* sty = nullptr;
     int B = 1;
+    int ksplit = 0;                // split K (row-split kernel, a 32-cout layer): ksplit "slabs" each contract Cin/ksplit input channels into
+                                   // output channels [32 s, 32 s + 32) of a [.., 32 * ksplit] tensor (partial sums, summed by sum_parts_lrelu_k)
+    const float* bias = nullptr;   // override of the layer's bias (split K: [32 * ksplit] = the bias, then zeros)
 };
 
 template <int BN, int TAPS, int EPI>
@@ -341,6 +345,7 @@ hipError_t wsplit_attr() {
 #define UWS(EPI) {32, 10, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 1>, "conv_upw_sc<" #EPI ">", &wino_attr<EPI, UPW_NW, 1, 1>}
 const ConvKey WINO_TABLE[] = {
     WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
+    WK(0),      // raw partial sums of a split-K launch
     // KernelFilter 32->512 convs with the folded dynamic filter (+ residual, + AdaIN after Filter3)
     WK(E_RES), WK(E_RES | E_NORM2),
     // ResidualBlock.conv1 behind the nearest-x2 upsample (forward pass / preparation pass)
@@ -361,6 +366,9 @@ int conv(rrv_handle h, const ConvCall& c) {
         for (const ConvKey& e : WINO_TABLE)
             if (e.EPI == c.epi && e.UPS == (int)c.ups && (e.TAPS == 10) == fuse_sc) { k = &e; wino = true; break; }
     }
+    const int ks = c.ksplit > 1 ? c.ksplit : 1;
+    if (ks > 1 && !(wino && !c.ups && w.Cout == 32 && (w.Cin % (32 * ks)) == 0 && c.bias))
+        return fail(h, RRV_E_ARG, "conv: split K needs the row-split kernel, a 32-cout layer, an even number of 16-channel chunks per slice and a split bias");
     if (!k && !c.ups) {
         for (const ConvKey& e : CONV_TABLE)
             if (e.BN == w.BN && e.TAPS == w.taps && e.EPI == c.epi) { k = &e; break; }
@@ -380,9 +388,13 @@ int conv(rrv_handle h, const ConvCall& c) {
         p.sc_out = c.sc_out->p;
     }
     if (!p.wpk) return fail(h, RRV_E_ARG, "conv: weights not packed for this kernel"); p.n1 = c.n1; p.n2 = c.n2; p.sty = c.sty;
+    if (c.bias) p.bias = c.bias;
+    if (ks > 1) {       // the [1 slab][Cin/16 chunks] weight pack read as [ks slabs][Cin/16/ks chunks]: slab s = input channel slice s
+        p.Cin = w.Cin / ks; p.cstride = w.Cin; p.cin_slab_step = w.Cin / ks; p.Cout = 32 * ks;
+    }
     if (c.res) { p.res = c.res->p; p.Hr = c.res->H; p.Wr = c.res->W; }
     p.tiles_x = (c.W + 15) / 16; p.tiles_y = (c.H + 7) / 8;
-    if (c.in->C != w.Cin || c.out->C != w.Cout) return fail(h, RRV_E_ARG, "conv: channel mismatch");
+    if (c.in->C != w.Cin || c.out->C != w.Cout * ks) return fail(h, RRV_E_ARG, "conv: channel mismatch");
     const int eh = c.ups ? c.H / 2 : c.H, ew = c.ups ? c.W / 2 : c.W;
     if (c.in->H != eh || c.in->W != ew) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
@@ -397,7 +409,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B), (unsigned)(w.Cout / w.BN));
     if (wino) {   // persistent workgroups (one per CU; two for the upsample-fused form), walking tiles_x*tiles_y*B*(Cout/32) work items
-        const unsigned slabs = (unsigned)(w.Cout / 32);
+        const unsigned slabs = (unsigned)(w.Cout / 32) * ks;
         const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B) * slabs;
         const unsigned resident = (unsigned)h->n_cus * (c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);
         grid = dim3(items < resident ? items : resident, 1);
@@ -408,12 +420,13 @@ int conv(rrv_handle h, const ConvCall& c) {
     // algorithmic FLOPs = the reference's direct convolution (taps multiply-adds per output);
     // executed: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 outputs (4 per pixel), the upsample-fused form 9 (2.25 per pixel)
     // (a fused shortcut adds its own 1x1 conv at the input resolution: one more GEMM position, 2.5 per output pixel)
-    const double flops_sc = fuse_sc ? 2.0 * c.B * c.in->H * c.in->W * (double)w.Cout * w.Cin : 0.0;
-    const double flops = 2.0 * px * w.Cout * w.Cin * w.taps + flops_sc;
-    const double flops_exec = 2.0 * px * w.Cout * w.Cin * (wino ? (c.ups ? (fuse_sc ? 2.5 : 2.25) : 4.0) : (double)w.taps);
-    const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * w.Cin + (double)c.B * oh * ow * w.Cout +
-                                (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * w.Cin * w.taps +
-                                (fuse_sc ? (double)c.B * c.in->H * c.in->W * w.Cout + (double)w.Cout * w.Cin : 0.0));
+    const double cin = w.Cin;
+    const double flops_sc = fuse_sc ? 2.0 * c.B * c.in->H * c.in->W * (double)w.Cout * cin : 0.0;
+    const double flops = 2.0 * px * w.Cout * cin * w.taps + flops_sc;
+    const double flops_exec = 2.0 * px * w.Cout * cin * (wino ? (c.ups ? (fuse_sc ? 2.5 : 2.25) : 4.0) : (double)w.taps);
+    const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * cin + (double)c.B * oh * ow * w.Cout +
+                                (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * cin * w.taps +
+                                (fuse_sc ? (double)c.B * c.in->H * c.in->W * w.Cout + (double)w.Cout * cin : 0.0));
     hipStream_t s = h->stream;
     ConvFn fn = k->fn;
     if (h->profiling) {   // "<kernel>@CinxCout@HxW": bench.py groups by the part before '@'
@@ -518,10 +531,15 @@ int chan_stats(rrv_handle h, const Tens& t, int mode, float* out) {
 int pointwise(rrv_handle h, const Tens& x, Tens& y, const float* mean, const float* scale, bool div, const Tens* res,
               int res_mode, const float* smean, const float* sstd, const float* lo = nullptr, const float* hi = nullptr) {
     PointP p{x.p, y.p, x.B, x.H, x.W, x.C, mean, scale, div ? 1 : 0, res ? res->p : nullptr, res_mode,
-             res ? res->H : 0, res ? res->W : 0, smean, sstd, lo, hi};
-    const long total = (long)x.B * x.H * x.W * (x.C / 4);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
+             res ? res->H : 0, res ? res->W : 0, smean, sstd, lo, hi, 1};
+    // image rows x segments per row: ~4 float4 per thread, at most 16384 blocks (further rows are strided)
+    int rows = x.B * x.H;
+    int segs = (x.W * (x.C / 4) + 1023) / 1024;
+    if (segs < 1) segs = 1;
+    while (rows * segs > 16384 && segs > 1) --segs;
+    if (rows * segs > 16384) rows = 16384 / segs;
+    p.segs = segs;
+    const int blocks = rows * segs;
     return launch(h, "pointwise", 0, 0, [&] { hipLaunchKernelGGL(pointwise_k, dim3(blocks), dim3(256), 0, h->stream, p); });
 }
 
@@ -655,6 +673,29 @@ int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {
     return RRV_OK;
 }
 
+// KernelFilter.down_sample with the folded filter F1 + LeakyReLU (cur -> d.d).  At the relu4_1 resolution a frame has few
+// 16x16 pixel tiles (25 at 512x512, 81 at 1024x1024) and the layer a single cout slab, so one launch fills a fraction of
+// the chip with one long item per workgroup.  The contraction over the 512 input channels is therefore split into
+// slices (split K): each slice is its own item with a raw partial output, a small kernel sums them and applies the
+// LeakyReLU.  The split depends on the FRAME's tile count only, so a frame's arithmetic is the same in any batch.
+int filter_down(rrv_handle h, const Tens* cur, DecPlan& d, int f, int B) {
+    const int tiles = ((cur->W + 15) / 16) * ((cur->H + 15) / 16);
+    const int split = tiles * 8 <= 320 ? 8 : (tiles * 4 <= 512 ? 4 : (tiles * 2 <= 256 ? 2 : 1));
+    if (split == 1) {
+        ConvCall c{cur, &d.d, &h->cur->fold_down[f], cur->H, cur->W}; c.B = B; c.epi = E_LRELU;
+        return conv(h, c);
+    }
+    Tens& t = d.dpart;
+    if (!t.p || t.B < B || t.H != d.d.H || t.W != d.d.W || t.C != 32 * split) RCHK(talloc(h, &t, d.d.B, d.d.H, d.d.W, 32 * split));
+    ConvCall c{cur, &t, &h->cur->fold_down[f], cur->H, cur->W}; c.B = B; c.epi = 0; c.ksplit = split; c.bias = h->cur->fold_down[f].bias;
+    RCHK(conv(h, c));
+    const long npix = (long)B * (d.d.H + 2) * (d.d.W + 2);
+    return launch(h, "sum_parts", 0, 4.0 * 32 * (split + 1) * npix, [&] {
+        const long nb = (npix * 8 + 255) / 256;
+        hipLaunchKernelGGL(sum_parts_lrelu_k, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, h->stream, (const float*)t.p, d.d.p, split, npix);
+    });
+}
+
 struct Win { int y0, x0, y1, x1; };     // output window in pixels, tile aligned; y1 == 0: everything
 
 int resblock_frame(rrv_handle h, int B, const char* blk, const Tens& in, Tens& xs, Tens& a, Tens& o, int n1, int n2, int nada, int sty,
@@ -720,7 +761,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     const Tens* cur = &e.c41;
     Tens* fo[3] = {&d.f1, &d.f2, &d.f3};
     for (int f = 0; f < 3; ++f) {
-        ConvCall c{cur, &d.d, &h->cur->fold_down[f], cur->H, cur->W}; c.B = B; c.epi = E_LRELU; RCHK(conv(h, c));
+        RCHK(filter_down(h, cur, d, f, B));
         ConvCall u{&d.d, fo[f], &h->cur->fold_up[f], cur->H, cur->W}; u.B = B;
         u.epi = E_RES | (f == 2 ? E_NORM2 : 0); u.res = cur;
         if (f == 2) { u.n2 = st + SL.norm[N_DEC1]; u.sty = st + SL.sty[3]; }
@@ -866,18 +907,18 @@ int compute_style(rrv_handle h, int sid, const Tens& content) {
 // replaced by nine rectangle sums and a 64 x 4608 product (prep_kernels.h), their style half is cached per style.
 int chan_stats1(rrv_handle h, const Tens& t, float* out) {
     const long npix = (long)t.B * t.H * t.W;
-    int nblk = (int)((npix + 255) / 256);
-    if (nblk > 1024) nblk = 1024;
+    int nblk = t.B * t.H;                    // whole rows per block; ~2 blocks per CU keep the merge short
+    if (nblk > 512) nblk = 512;
     if (nblk < 1) nblk = 1;
-    const int ppb = (int)((npix + nblk - 1) / nblk);
     if (t.C > 512) return fail(h, RRV_E_ARG, "chan_stats: more than 512 channels");
     if (!h->stat_part) HIPCHK(hipMalloc((void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
-    StatP sp{t.p, t.B, t.H, t.W, t.C, nullptr, h->stat_part, 0, ppb};
+    StatP sp{t.p, t.B, t.H, t.W, t.C, nullptr, h->stat_part, 0, 0};
     RCHK(launch(h, "chan_stat1", 0, 4.0 * npix * t.C, [&] { hipLaunchKernelGGL(chan_stat1_k, dim3(nblk), dim3(256), 0, h->stream, sp); }));
     return launch(h, "chan_stat1_final", 0, 0, [&] {
         hipLaunchKernelGGL(chan_stat1_final_k, dim3((t.C + 3) / 4), dim3(256), 0, h->stream, (const double*)h->stat_part, nblk, t.C, out);
     });
 }
+
 int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* d_out) {
     StyleState& S = h->styles[0];
     float* st = S.blob;
@@ -886,7 +927,8 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
     RCHK(dec_plan(h, h->dec[0], 1, H, W));
     EncPlan& e = h->enc_frame[0];
     DecPlan& d = h->dec[0];
-    if (!h->frame_S) { RCHK(dalloc(h, &h->frame_S, 9 * 512)); RCHK(dalloc(h, &h->frame_cmean, 64)); }
+    constexpr int RS_PARTS = 1;      // (splitting the pixels over several blocks per channel quad measured slower: the merge in pred_mean_k costs more)
+    if (!h->frame_S) { RCHK(dalloc(h, &h->frame_S, RS_PARTS * 9 * 512)); RCHK(dalloc(h, &h->frame_cmean, 64)); }
     RCHK(run_encoder(h, e, d_img, 0, nullptr, nullptr, 1));
     Tens c41 = e.c41; c41.B = 1;          // views of one image (plans are grow-only)
     const int hh = c41.H, ww = c41.W;
@@ -901,14 +943,14 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
     Tens* fo[3] = {&f1, &f2, &f3};
     for (int f = 0; f < 3; ++f) {
         RCHK(launch(h, "rect_sums", 0, 4.0 * hh * ww * 512, [&] {
-            hipLaunchKernelGGL(rect_sums_k, dim3(128), dim3(256), 0, h->stream, (const float*)cur->p, hh, ww, 512, h->frame_S);
+            hipLaunchKernelGGL(rect_sums_k, dim3(128, RS_PARTS), dim3(256), 0, h->stream, (const float*)cur->p, hh, ww, 512, h->frame_S);
         }));
         for (int g = 0; g < 2; ++g) {
             char key[96];
             snprintf(key, sizeof key, "Decoder.Filter%d.F%d.down_sample.0", f + 1, g + 1);
             const ConvW& wp = h->conv[key];
             RCHK(launch(h, "pred_mean", 2.0 * 32 * 4608, 0, [&] {
-                hipLaunchKernelGGL(pred_mean_k, dim3(32), dim3(256), 0, h->stream, (const float*)wp.raw, (const float*)wp.bias, (const float*)h->frame_S, 512,
+                hipLaunchKernelGGL(pred_mean_k, dim3(32), dim3(256), 0, h->stream, (const float*)wp.raw, (const float*)wp.bias, (const float*)h->frame_S, RS_PARTS, 512,
                                    1.0 / ((double)hh * ww), h->frame_cmean + 32 * g);
             }));
             hipLaunchKernelGGL(fc_filter_k, dim3(4), dim3(256), 0, h->stream, (const float*)h->fc_w[2 * f + g], (const float*)h->fc_b[2 * f + g],
@@ -916,7 +958,7 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
             HIPCHK(hipGetLastError());
         }
         RCHK(fold_filters(h, st, f, false));
-        ConvCall c{cur, &d.d, &h->cur->fold_down[f], hh, ww}; c.epi = E_LRELU; RCHK(conv(h, c));
+        RCHK(filter_down(h, cur, d, f, 1));
         ConvCall u{&d.d, fo[f], &h->cur->fold_up[f], hh, ww};
         u.epi = E_RES | (f == 2 ? E_NORM2 : 0); u.res = cur;
         if (f == 2) { u.n2 = st + SL.norm[N_DEC1]; u.sty = st + SL.sty[3]; }     // identity norm, then * style_std + style_mean
@@ -1155,6 +1197,7 @@ static void free_plans(rrv_handle h) {
         for (Tens* t : {&e->c11, &e->p1, &e->c21, &e->p2, &e->c31, &e->c32, &e->c33, &e->p3, &e->c41}) tfree(t);
     for (DecPlan& d : h->dec) {
         for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2}) tfree(t);
+        tfree(&d.dpart);
         if (d.pre) { if (h->last_pre == d.pre) h->last_pre = nullptr; (void)hipFree(d.pre); d.pre = nullptr; }
         d.B = d.H = d.W = 0;
     }
@@ -1316,7 +1359,7 @@ int rrv_finalize_weights(rrv_handle h) {
         for (auto& set : h->sets) {
             ConvW& fd = set.fold_down[f];
             fd.Cout = 32; fd.Cin = 512; fd.taps = 9; fd.BN = 32;
-            RCHK(dalloc(h, &fd.raw, 32 * 512 * 9)); RCHK(dalloc(h, &fd.pk, 32 * 512 * 9)); RCHK(dalloc(h, &fd.bias, 32));
+            RCHK(dalloc(h, &fd.raw, 32 * 512 * 9)); RCHK(dalloc(h, &fd.pk, 32 * 512 * 9)); RCHK(dalloc(h, &fd.bias, 256));   // bias[32], then zeros: the split-K slabs' bias
             ConvW& fu = set.fold_up[f];
             fu.Cout = 512; fu.Cin = 32; fu.taps = 9; fu.BN = 128;
             RCHK(dalloc(h, &fu.raw, 512 * 32 * 9)); RCHK(dalloc(h, &fu.pk, 512 * 32 * 9));
