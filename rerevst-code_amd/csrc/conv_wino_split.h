@@ -54,6 +54,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     const int tg = wave >> 1;                    // tile group: output rows 4*tg .. 4*tg+3 of the workgroup tile
     const int half = wave & 1;                   // transform rows {0,1} / {3,2}; finishes output row `half` of each tile
     const float sgn = half ? -1.f : 1.f;
+    if ((ABL & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);       // microbench: static priority for the second-dispatched half
+    if ((ABL & 128) && half) __builtin_amdgcn_s_setprio(1);          // microbench: priority for one wave of every pair
     const int nchunks = p.Cin >> 4;              // even
     const int cs = p.cstride ? p.cstride : p.Cin;    // channels per pixel in memory (split K: the launch contracts a slice of them)
     const int n_ntiles = p.Cout >> 5;

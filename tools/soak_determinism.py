@@ -26,7 +26,7 @@ for S in (512, 200):
         s.transfer_batch_device(d_in.data_ptr(), B, P, P, d_out[1 + it % 3].data_ptr())
         if it % 3 == 2 or it == N - 1:
             s.sync()
-            for k in range(1, 4):
+            for k in range(1, 2 + it % 3):          # the buffers written since the last check
                 if not torch.equal(d_out[k], ref): bad += 1
             d_out[1:].zero_()
     print("size %d: %d batches of %d frames, mismatching buffers: %d" % (S, N, B, bad))

@@ -66,11 +66,13 @@ void layer(const char* name, int B, int H, int W, int Cin, int Cout) {
     const double fl = 2.0 * B * H * W * (double)Cin * Cout * 4;      // executed (Winograd) FLOPs
     const int it = 10;
     run<EPI, 0>(p, 40);      // clocks up before anything is compared
-    float t0 = 1e9f, t4 = 1e9f, t32 = 1e9f, t1 = 1e9f, t2 = 1e9f, t64 = 1e9f;
+    float t0 = 1e9f, t4 = 1e9f, t32 = 1e9f, t1 = 1e9f, t2 = 1e9f, t64 = 1e9f, t8 = 1e9f, t128 = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {      // round-robin, best of three: no variant profits from running later
         t0 = fminf(t0, run<EPI, 0>(p, it)); t4 = fminf(t4, run<EPI, 4>(p, it)); t32 = fminf(t32, run<EPI, 32>(p, it));
         t1 = fminf(t1, run<EPI, 1>(p, it)); t2 = fminf(t2, run<EPI, 2>(p, it)); t64 = fminf(t64, run<EPI, 64>(p, it));
+        t8 = fminf(t8, run<EPI, 8>(p, it)); t128 = fminf(t128, run<EPI, 128>(p, it));
     }
+    printf("%-24s EPI %3d: s_setprio(1) for waves 4-7: %.1f TF | for the odd wave of each pair: %.1f TF (as is %.1f)\n", name, EPI, fl / t8 / 1e9, fl / t128 / 1e9, fl / t0 / 1e9);
     printf("%-24s EPI %3d: %.4f ms = %.1f TF executed (%.3f of peak) | no stores %.1f | no residual loads %.1f | no epilogue %.1f | no loads %.1f | no K-loop barriers %.1f\n",
            name, EPI, t0, fl / t0 / 1e9, fl / t0 / 1e9 / 157.3, fl / t4 / 1e9, fl / t64 / 1e9, fl / t32 / 1e9, fl / t1 / 1e9, fl / t2 / 1e9);
     long long* dbg; CK(hipMalloc(&dbg, (size_t)256 * 8 * 6 * 8));
