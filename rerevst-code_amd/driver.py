@@ -143,9 +143,50 @@ def stylize_files(model, style_path, frame_paths, out_dir, video_path=None, fps=
     return written
 
 
+def stylize_files_multistyle(model, style_paths, frame_paths, out_dir, video_path=None, fps=24, chunk=16, style_size=(384, 384), log=print):
+    """"Multi-style Interpolation/test.py" on files (VideoStylization :40-111 + the loop :114-131): styles resized to
+    384x384, every frame padded and encoded once (features cached by the model), every 16th + the last feature sampled,
+    then frame i with the weight ramp; output frames are numbered %d.png as the reference writes them (:131)."""
+    video = __import__("importlib").import_module("rerevst-code_amd.video")
+    os.makedirs(out_dir, exist_ok=True)
+    n, S = len(frame_paths), len(style_paths)
+    model.prepare_style([video.resize_bilinear(read_image_bgr(p), style_size) for p in style_paths])
+    tool = video.ReshapeTool()
+    shapes, feats = [], []
+    for i, path in enumerate(frame_paths):
+        f = read_image_bgr(path)
+        shapes.append(f.shape)
+        feats.append(model.generate_content_features(tool.process(f)))
+    log("Encoded %d frames; statistics from %d of them" % (n, len(video.sample_indices_multistyle(n))))
+    model.clean()
+    for i in video.sample_indices_multistyle(n):
+        model.add_patch(feats[i])
+    model.compute_norm()
+    many = getattr(model, "transfer_many", None)          # absent on a model with the reference's surface only
+    written, writer = [], None
+    for c0 in range(0, n, chunk):
+        idx = list(range(c0, min(n, c0 + chunk)))
+        wts = [video.ramp_weights(i, n, S) for i in idx]
+        styled = many([feats[i] for i in idx], wts) if many is not None else [model.transfer(feats[i], w) for i, w in zip(idx, wts)]
+        for j, i in enumerate(idx):
+            H, W, _ = shapes[i]
+            img = styled[j][64:64 + H, 64:64 + W, :]
+            out_path = os.path.join(out_dir, "%d.png" % i)
+            write_image_bgr(out_path, img)
+            written.append(out_path)
+            if video_path:
+                if writer is None:
+                    writer = MJPGWriter(video_path, fps, W, H)
+                writer.write(img)
+        log("stylized frames %d..%d of %d" % (idx[0], idx[-1], n))
+    if writer is not None:
+        writer.release()
+    return written
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
-    ap.add_argument("--style", required=True)
+    ap.add_argument("--style", required=True, nargs="+", help="one style image, or several for multi-style interpolation")
     ap.add_argument("--frames", required=True, help="glob pattern of the content frames")
     ap.add_argument("--checkpoint", required=True, help="style_net-TIP-final.pth (or 'synthetic' for seeded weights)")
     ap.add_argument("--out", required=True, help="directory for the stylized frames")
@@ -154,12 +195,17 @@ def main(argv=None):
     ap.add_argument("--no-global", action="store_true", help="per-frame statistics (use_Global=False)")
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
-    if not os.path.exists(args.style):
-        sys.exit("Style image %s not exists" % args.style)            # generate_real_video.py:93-94
+    for sp in args.style:
+        if not os.path.exists(sp):
+            sys.exit("Style image %s not exists" % sp)                # generate_real_video.py:93-94, test.py:51-52
     pkg = __import__("importlib").import_module("rerevst-code_amd")
     ckpt = pkg.synthetic_weights(0) if args.checkpoint == "synthetic" else args.checkpoint
-    model = pkg.Stylization(ckpt, cuda=True, use_Global=not args.no_global, device=args.device)
-    stylize_files(model, args.style, list_frames(args.frames), args.out, args.video, args.fps)
+    if len(args.style) > 1:     # "Multi-style Interpolation/test.py"
+        model = pkg.MultiStyleStylization(ckpt, cuda=True, style_num=len(args.style), device=args.device)
+        stylize_files_multistyle(model, args.style, list_frames(args.frames), args.out, args.video, args.fps)
+    else:
+        model = pkg.Stylization(ckpt, cuda=True, use_Global=not args.no_global, device=args.device)
+        stylize_files(model, args.style[0], list_frames(args.frames), args.out, args.video, args.fps)
     model.close()
 
 

@@ -85,3 +85,25 @@ def test_reference_script_flow_with_the_oracle(tmp_path, pkg, oracle):
         assert got.shape == (24, 32, 3)
         np.testing.assert_array_equal(got, D.to_uint8(ref[i]))
     assert os.path.getsize(str(tmp_path / "v.avi")) > 212
+
+
+def test_multistyle_script_flow_with_the_oracle(tmp_path, pkg, oracle):
+    """"Multi-style Interpolation/test.py" on files: styles resized, frames padded and encoded once, sampled features,
+    weight ramp, crop, frames written as %d.png — with the CPU oracle as the model."""
+    src, out = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    frames = [pkg.synth_frame(i, 24, 32, kind="smooth") for i in range(3)]
+    for i, f in enumerate(frames):
+        D.write_image_bgr(str(src / ("f%02d.png" % i)), f)
+    styles = [pkg.synth_style(20, 28, kind="smooth", seed=5), pkg.synth_style(28, 20, kind="smooth", seed=6)]
+    for k, s in enumerate(styles):
+        D.write_image_bgr(str(tmp_path / ("style%d.png" % k)), s)
+    model = oracle.MultiStylization(pkg.synthetic_weights(0), 2)
+    written = D.stylize_files_multistyle(model, [str(tmp_path / "style0.png"), str(tmp_path / "style1.png")], D.list_frames(str(src / "*.png")),
+                                         str(out), video_path=str(tmp_path / "v.avi"), fps=12, style_size=(32, 32), log=lambda *_: None)
+    assert [os.path.basename(p) for p in written] == ["0.png", "1.png", "2.png"]
+    V = importlib.import_module("rerevst-code_amd.video")
+    ref = V.stylize_video_multistyle(oracle.MultiStylization(pkg.synthetic_weights(0), 2), frames, styles, style_size=(32, 32))
+    for i, p in enumerate(written):
+        np.testing.assert_array_equal(D.read_image_bgr(p), D.to_uint8(ref[i]))
+    assert os.path.getsize(str(tmp_path / "v.avi")) > 212

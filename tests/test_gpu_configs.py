@@ -200,3 +200,27 @@ def test_multistyle_batched_transfer_equals_per_frame(pkg, weights, oracle):
     ref0 = pkg.Stylization.transfer(s, frames[1], style_weight=[1.0, 0.0, 0.0, 0.0])
     assert np.abs(one - ref0).max() <= 1e-3
     s.close()
+
+
+def test_multistyle_command_line_driver_end_to_end(tmp_path, pkg, weights):
+    """python -m rerevst-code_amd.driver with several --style images = "Multi-style Interpolation/test.py" on files:
+    same frames as the Python-level flow (video.stylize_video_multistyle with the HIP MultiStyleStylization)."""
+    D = importlib.import_module("rerevst-code_amd.driver")
+    V = importlib.import_module("rerevst-code_amd.video")
+    src = tmp_path / "in"
+    src.mkdir()
+    frames = [pkg.synth_frame(700 + i, 48, 64, kind="smooth") for i in range(5)]
+    for i, f in enumerate(frames):
+        D.write_image_bgr(str(src / ("f%03d.png" % i)), f)
+    styles = [pkg.synth_style(60, 44, kind="smooth", seed=20 + k) for k in range(3)]
+    paths = []
+    for k, s in enumerate(styles):
+        paths.append(str(tmp_path / ("style%d.png" % k)))
+        D.write_image_bgr(paths[-1], s)
+    D.main(["--style", *paths, "--frames", str(src / "*.png"), "--checkpoint", "synthetic", "--out", str(tmp_path / "out")])
+    m = pkg.MultiStyleStylization(weights, cuda=True, style_num=3)
+    ref = V.stylize_video_multistyle(m, frames, styles)
+    m.close()
+    for i in range(5):
+        got = D.read_image_bgr(str(tmp_path / "out" / ("%d.png" % i)))
+        assert np.abs(got.astype(np.int32) - D.to_uint8(ref[i]).astype(np.int32)).max() <= 1     # batched vs per-frame call order: same arithmetic, uint8 rounding ties
