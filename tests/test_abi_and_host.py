@@ -189,3 +189,28 @@ def test_oracle_torch_conv_backend_agrees(oracle):
     assert c.shape == a.shape and c.dtype == np.float32
     np.testing.assert_allclose(c, a, atol=2e-5)
     np.testing.assert_allclose(c0 + b, a, atol=2e-5)
+
+
+def test_bench_roofline_fields_from_event_rows():
+    """bench.py's roofline object: `achieved` / `frac` are the EXECUTED FLOPs of the dominant kernel over its HIP-event
+    time (never above 1), the reference's direct-form FLOPs are reported next to them; HBM-bound kernels carry a
+    fraction of the HBM peak instead."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    rows = []
+    for _ in range(8):        # (name, ms, algorithmic flops, algorithmic bytes, executed flops)
+        rows.append(("conv_upw_sc<E_LRELU | E_NORM1>@128x64@640x640", 1.0, 4.0e11, 8.0e8, 1.2e11))
+        rows.append(("conv_wino<E_RELU>@256x256@160x160", 0.5, 1.0e11, 3.0e8, 4.4e10))
+        rows.append(("conv_last", 0.25, 1.0e10, 8.0e8, 1.0e10))
+    roof, kern, layers = b.roofline_and_kernels(rows, 1, 64, 512)
+    assert roof["kernel"] == "conv_upw_sc<E_LRELU | E_NORM1>" and roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"
+    assert abs(roof["achieved"] - 120.0) < 1e-6 and abs(roof["frac"] - 120.0 / 157.3) < 1e-3 and roof["frac"] < 1.0
+    assert abs(roof["algorithmic_tflops"] - 400.0) < 1e-6 and abs(roof["algorithmic_speedup"] - 4.0 / 1.2) < 1e-2
+    assert roof["algorithmic_bytes_per_launch"] == 800000000 and abs(roof["avg_launch_ms"] - 1.0) < 1e-9
+    k = {r["kernel"]: r for r in kern}
+    assert k["conv_last"]["bound"] == "hbm" and abs(k["conv_last"]["frac_of_hbm_peak"] - 3200.0 / 8000.0) < 1e-3
+    assert k["conv_wino<E_RELU>"]["bound"] == "mfma" and abs(k["conv_wino<E_RELU>"]["frac_of_mfma_peak"] - 88.0 / 157.3) < 1e-3
+    assert abs(k["conv_last"]["ms_per_frame"] - 8 * 0.25 / 64) < 1e-4
+    assert b.roofline_and_kernels([], 0, 64, 512)[0] is None
