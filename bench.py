@@ -118,7 +118,7 @@ def roofline_and_kernels(rows, nprof, frames_per_step, size):
     kern = []
     tot_ms = sum(a[1] for a in agg.values())
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        hbm = name.startswith(HBM_KERNELS) or name in ("pointwise", "chan_stat", "chan_final")
+        hbm = name.startswith(HBM_KERNELS) or a[2] == 0      # no matrix work (statistics, pointwise, partial sums): bandwidth kernels
         k = {"kernel": name, "launches_per_step": a[0] / nprof, "ms_per_frame": round(a[1] / nprof / frames_per_step, 4),
              "bound": "hbm" if hbm else "mfma"}
         if a[1] > 0 and a[3] > 0:
@@ -237,7 +237,9 @@ def main():
     video = importlib.import_module("rerevst-code_amd.video")
     NS = args.multistyle
     S = args.size or (1024 if NS else 512)
-    NF = args.frames or {256: 100}.get(S, 300)
+    # BASELINE configs: 100 frames at 256x256, 300 at 512x512 / 1024x1024 on one GPU, 1200 frames at 512x512 over 8 GPUs
+    # (150 per GPU; kept for every N > 1 so that the work per GPU — and rank 0's preparation per GPU — is the same)
+    NF = args.frames or ({256: 100}.get(S, 300) if world == 1 else {256: 100}.get(S, 150) * world)
     P = video.padded_size(S)
     B = args.batch or max(8, min(128, (64 * 640 * 640) // (P * P) // 8 * 8))
     weights = pkg.synthetic_weights(0)
@@ -254,14 +256,15 @@ def main():
     model.set_pipeline(args.pipeline)
 
     # ---- once-per-video preparation on rank 0, state broadcast over RCCL ------------------
-    first = (rank * args.steps * B) % NF                       # this rank's shard of the (cyclic) video
+    lo, hi = video.shard_range(NF, rank, world)                # this rank's contiguous shard of the video
+    first, nshard = lo, max(1, hi - lo)
     t0 = time.time()
     blob = torch.empty(max(1, NS) * 17536, dtype=torch.float32, device=cdev)
     feats = None
     if NS:
         # features of this rank's frames, cached in HBM (rank 0 also needs the sampled ones for the statistics)
-        n_cached = min(NF, args.steps * B + args.warmup * B)
-        my_ids = [(first + i) % NF for i in range(n_cached)]
+        n_cached = min(nshard, args.steps * B + args.warmup * B)
+        my_ids = [first + i % nshard for i in range(n_cached)]
         styles = [video.resize_bilinear(pkg.synth_style(512, 512, kind="noise", seed=7 + k), (384, 384)) for k in range(NS)]   # test.py:53
         if rank == 0:
             model.prepare_style(styles)
@@ -297,11 +300,11 @@ def main():
     if NS:
         nW = len(feats)
         def step(i):
-            ks = [i * B + j for j in range(B)]           # global frame index -> the reference's weight ramp
-            model.transfer_many([feats[k % nW] for k in ks], [video.ramp_weights((first + k) % NF, NF, NS) for k in ks], out=h_out[i & 1])
+            ks = [(i * B + j) % nW for j in range(B)]    # position in the shard; global frame index -> the reference's weight ramp
+            model.transfer_many([feats[k] for k in ks], [video.ramp_weights(my_ids[k], NF, NS) for k in ks], out=h_out[i & 1])
     else:
-        n_batches = max(1, min(max(1, NF // B), args.steps))          # distinct batches kept resident in host memory
-        my_ids = [(first + i) % NF for i in range(n_batches * B)]
+        n_batches = max(1, min(max(1, nshard // B), args.steps))      # distinct batches kept resident in host memory
+        my_ids = [first + i % nshard for i in range(n_batches * B)]
         h_in = alloc((n_batches, B, P, P, 3), np.uint8)
         for k, i in enumerate(my_ids):
             h_in[k // B, k % B] = video.reflect_pad(pkg.synth_frame(i, S, S, kind="noise"), P, P)
