@@ -88,9 +88,10 @@ int rrv_set_state(rrv_handle h, const float* in, int n, int style_id);
 
 /* Stylization.transfer (test/framework.py:106-118): uint8 BGR HWC [H][W][3] in host
  * memory -> float32 BGR HWC [H][W][3] in 0..255 in host memory (includes the H2D / D2H crossings of
- * framework.py:109 `.to(device)` and :40 `.cpu()`).  H and W must be multiples of 8 (the reference accepts any size
- * and its output floors to a multiple of 8; its driver pads to multiples of 64) and (H+2)*(W+2)*64 < 2^31
- * (about 33 Mpixel per frame; RRV_E_ARG beyond).  Page-locked caller buffers (rrv_host_alloc / rrv_host_register)
+ * framework.py:109 `.to(device)` and :40 `.cpu()`).  Any H, W >= 8: as in the reference the three max pools floor the
+ * size, so out_bgr is [Ho][Wo][3] with Ho = 8*(H/8), Wo = 8*(W/8) (= [H][W][3] for the multiples of 64 the reference
+ * driver produces); (H+2)*(W+2)*64 < 2^31 (about 33 Mpixel per frame; RRV_E_ARG beyond).  The same holds for every
+ * other transfer entry (batch, device, blend, features, frame mode).  Page-locked caller buffers (rrv_host_alloc / rrv_host_register)
  * are DMA'd directly; pageable ones are staged through the library's own pinned buffers. */
 int rrv_transfer(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* out_bgr);
 

@@ -730,7 +730,10 @@ int run_last(rrv_handle h, const Tens& o2, int B, int H, int W, float* d_out, fl
 int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, float* d_out, const float* feat = nullptr,
                     const PadCrop* pc = nullptr) {
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
-    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
+    // Any frame size, as the reference: the three 2x2 max pools floor (H, W) to (H/8, W/8) and the decoder returns
+    // 8*(H/8) x 8*(W/8) pixels (test/style_network_global.py:271-281, :111-122) — the stylized frame is [Ho][Wo][3].
+    const int Ho = H / 8 * 8, Wo = W / 8 * 8;
+    if (Ho < 8 || Wo < 8) return fail(h, RRV_E_ARG, "transfer: frames must be at least 8 x 8 pixels");
     if (h->active_src == -1) return fail(h, RRV_E_STATE, "state not computed: call compute() (or set_state) before transfer()");
     if (B < 1 || B > 64) return fail(h, RRV_E_ARG, "transfer: batch must be in 1..64");
     // element indices inside one image are 32-bit in the kernels' epilogues: (H+2)(W+2) x 64 channels must stay below 2^31
@@ -747,7 +750,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         HIPCHK(hipStreamWaitEvent(h->stream, h->slot_ev[slot], 0));
     }
     RCHK(enc_plan(h, h->enc_frame[slot], B, H, W));
-    RCHK(dec_plan(h, h->dec[slot], B, H, W));
+    RCHK(dec_plan(h, h->dec[slot], B, Ho, Wo));
     DecPlan& d = h->dec[slot];
     EncPlan& e = h->enc_frame[slot];
     const float* st = h->cur->active;
@@ -779,7 +782,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         auto grow = [&](const Win& w, int halo) {
             auto lo = [&](int v) { v -= halo; return v < 0 ? 0 : (v & ~15); };
             auto hi = [&](int v, int lim) { v = (v + halo + 15) & ~15; const int l = (lim + 15) & ~15; return v > l ? l : v; };
-            return Win{lo(w.y0), lo(w.x0), hi(w.y1, H), hi(w.x1, W)};
+            return Win{lo(w.y0), lo(w.x0), hi(w.y1, Ho), hi(w.x1, Wo)};
         };
         const Win crop{pc->top, pc->left, pc->top + pc->src_H, pc->left + pc->src_W};
         wl = grow(crop, 0);        // conv_last output tiles
@@ -787,7 +790,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         wa = grow(wo, 1);          // slice2.conv1 output (and, halved, the shortcut) feeding that
     }
     RCHK(resblock_frame(h, B, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr));
-    RCHK(run_last(h, d.o2, B, H, W, d_out, d.pre, pc, roi ? &wl : nullptr));
+    RCHK(run_last(h, d.o2, B, Ho, Wo, d_out, d.pre, pc, roi ? &wl : nullptr));
     if (h->caller_sync) {    // ... and whatever the caller queues next sees our output
         HIPCHK(hipEventRecord(h->slot_ev[slot], h->stream));
         HIPCHK(hipStreamWaitEvent(h->caller_stream, h->slot_ev[slot], 0));
@@ -923,8 +926,9 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
     StyleState& S = h->styles[0];
     float* st = S.blob;
     h->stream = h->streams[0];
+    const int Ho = H / 8 * 8, Wo = W / 8 * 8;       // any frame size, as in transfer_device
     RCHK(enc_plan(h, h->enc_frame[0], 1, H, W));
-    RCHK(dec_plan(h, h->dec[0], 1, H, W));
+    RCHK(dec_plan(h, h->dec[0], 1, Ho, Wo));
     EncPlan& e = h->enc_frame[0];
     DecPlan& d = h->dec[0];
     constexpr int RS_PARTS = 1;      // (splitting the pixels over several blocks per channel quad measured slower: the merge in pred_mean_k costs more)
@@ -984,7 +988,7 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
         RCHK(pointwise(h, *b.o, *b.o, st + SL.norm[b.nada], st + SL.norm[b.nada] + b.cout, false, nullptr, 0, st + SL.sty[b.sty], st + SL.sty[b.sty] + b.cout));
         in = b.o;
     }
-    RCHK(run_last(h, o2, 1, H, W, d_out, d.pre, nullptr));
+    RCHK(run_last(h, o2, 1, Ho, Wo, d_out, d.pre, nullptr));
     if (h->debug) RCHK(debug_verify(h, "transfer (frame mode)"));
     return RRV_OK;
 }
@@ -1641,13 +1645,15 @@ static bool is_pinned(const void* ptr, size_t bytes) {
 static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out, bool pad_on_device = false) {
     if (!h || !frames || !out || B < 1) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
-    const size_t fb = (size_t)H * W * 3;
+    const size_t fb = (size_t)H * W * 3;                                   // input bytes per frame
+    const size_t fo = pad_on_device ? fb : (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;   // output floats per frame (any input size: 8*(H/8) x 8*(W/8))
     const int sub = pad_on_device ? host_sub(B, (H + 128 + 63) / 64 * 64, (W + 128 + 63) / 64 * 64) : host_sub(B, H, W);
     {   // refuse oversized frames before any staging buffer is sized for them
         const double ph = pad_on_device ? (double)((H + 128 + 63) / 64 * 64) : (double)H, pw = pad_on_device ? (double)((W + 128 + 63) / 64 * 64) : (double)W;
-        if (H < 1 || W < 1 || (ph + 2) * (pw + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
+        if (H < 1 || W < 1 || (!pad_on_device && (H < 8 || W < 8))) return fail(h, RRV_E_ARG, "transfer: frames must be at least 8 x 8 pixels");
+        if ((ph + 2) * (pw + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
     }
-    const bool in_pin = is_pinned(frames, (size_t)B * fb), out_pin = is_pinned(out, (size_t)B * fb * sizeof(float));
+    const bool in_pin = is_pinned(frames, (size_t)B * fb), out_pin = is_pinned(out, (size_t)B * fo * sizeof(float));
     RCHK(sync_all(h));
     const int nchunk = (B + sub - 1) / sub;
     const int nsets = nchunk < HOST_SETS ? nchunk : HOST_SETS;
@@ -1674,7 +1680,7 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
     auto drain = [&](int k) -> int {       // sub-batch k delivered (its staging set is free again)
         auto& st = h->hstage[k % HOST_SETS];
         HIPCHK(hipEventSynchronize(st.out_done));
-        if (!out_pin) host_copy(out + (size_t)k * sub * fb, st.pin_out, (size_t)count(k) * fb * sizeof(float));
+        if (!out_pin) host_copy(out + (size_t)k * sub * fo, st.pin_out, (size_t)count(k) * fo * sizeof(float));
         return RRV_OK;
     };
     int rc = RRV_OK;
@@ -1693,9 +1699,9 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
             h->next_slot = slot;
             rc = pad_on_device ? rrv_transfer_frames_device(h, st.d_in, nb, H, W, st.d_out) : rrv_transfer_batch_device(h, st.d_in, nb, H, W, st.d_out);
             if (rc != RRV_OK) break;
-            HIPCHK(hipMemcpyAsync(out_pin ? (void*)out : (void*)st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, cs));
+            HIPCHK(hipMemcpyAsync(out_pin ? (void*)out : (void*)st.pin_out, st.d_out, (size_t)nb * fo * sizeof(float), hipMemcpyDeviceToHost, cs));
             HIPCHK(hipStreamSynchronize(cs));
-            if (!out_pin) host_copy(out, st.pin_out, (size_t)nb * fb * sizeof(float));
+            if (!out_pin) host_copy(out, st.pin_out, (size_t)nb * fo * sizeof(float));
             h->next_slot = 0;
             return RRV_OK;
         }
@@ -1709,7 +1715,7 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
         if (rc != RRV_OK) break;
         HIPCHK(hipEventRecord(st.k_done, cs));
         HIPCHK(hipStreamWaitEvent(h->copy_out, st.k_done, 0));
-        HIPCHK(hipMemcpyAsync(out_pin ? (void*)(out + (size_t)k * sub * fb) : (void*)st.pin_out, st.d_out, (size_t)nb * fb * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
+        HIPCHK(hipMemcpyAsync(out_pin ? (void*)(out + (size_t)k * sub * fo) : (void*)st.pin_out, st.d_out, (size_t)nb * fo * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
         HIPCHK(hipEventRecord(st.out_done, h->copy_out));
     }
     if (rc != RRV_OK) { (void)sync_all(h); h->next_slot = 0; return rc; }
@@ -1786,7 +1792,6 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* wts, int ns
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
     const rrv_ctx::Feature& ft = h->features[feature_id];
-    if ((ft.H % 8) || (ft.W % 8)) return fail(h, RRV_E_ARG, "transfer: feature of a frame whose sides are not multiples of 8");
     BlendP bp{};
     bp.n = ns; bp.out = h->cur->active; bp.count = RRV_STATE_FLOATS;
     for (int s = 0; s < ns; ++s) {
@@ -1797,7 +1802,7 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* wts, int ns
     HIPCHK(hipGetLastError());
     for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f, false));
     h->active_src = -2;
-    const size_t n = (size_t)ft.H * ft.W * 3;
+    const size_t n = (size_t)(ft.H / 8 * 8) * (ft.W / 8 * 8) * 3;
     if (h->d_outf_cap < n) {
         if (h->d_outf) (void)hipFree(h->d_outf);
         h->d_outf = nullptr; h->d_outf_cap = 0;
@@ -1824,9 +1829,8 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
     const int H = h->features[ids[0]].H, W = h->features[ids[0]].W;
     for (int i = 1; i < n; ++i)
         if (h->features[ids[i]].H != H || h->features[ids[i]].W != W) return fail(h, RRV_E_ARG, "transfer: features of one call must share their size");
-    if ((H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: feature of a frame whose sides are not multiples of 8");
     RCHK(sync_all(h));
-    const size_t npx = (size_t)H * W * 3;
+    const size_t npx = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
     const bool out_pin = is_pinned(out, (size_t)n * npx * sizeof(float));
     const int nslots = (h->profiling || h->n_slots < 2 || n < 2) ? 1 : 2;
     for (int i = 0; i < nslots; ++i) {
@@ -1898,14 +1902,15 @@ int rrv_release_features(rrv_handle h) {
 int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame, int H, int W, float* out) {
     if (!h || !frame || !out) return RRV_E_ARG;
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
-    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(h, RRV_E_ARG, "transfer: H and W must be positive multiples of 8");
+    if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "transfer: frames must be at least 8 x 8 pixels");
     HIPCHK(hipSetDevice(h->dev));
     StyleState& S = h->styles[0];
     if (!S.prepared) return fail(h, RRV_E_STATE, "prepare_style has not been called");
     RCHK(sync_all(h));
-    const size_t n = (size_t)H * W * 3;
-    RCHK(ensure_u8(h, n));
-    HIPCHK(hipMemcpyAsync(h->d_u8, frame, n, hipMemcpyHostToDevice, h->stream));
+    const size_t nin = (size_t)H * W * 3;
+    const size_t n = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;       // the stylized frame is 8*(H/8) x 8*(W/8)
+    RCHK(ensure_u8(h, nin));
+    HIPCHK(hipMemcpyAsync(h->d_u8, frame, nin, hipMemcpyHostToDevice, h->stream));
     if (h->d_outf_cap < n) {
         if (h->d_outf) (void)hipFree(h->d_outf);
         h->d_outf = nullptr; h->d_outf_cap = 0;

@@ -140,7 +140,7 @@ class Stylization():
         blended first (stylization.py:94-100)."""
         a = _u8_image(frame, "frame")
         H, W = a.shape[:2]
-        out = np.empty((H, W, 3), dtype=np.float32)
+        out = np.empty((H // 8 * 8, W // 8 * 8, 3), dtype=np.float32)     # the max pools floor the size, as in the reference
         if not self.use_Global:
             self._chk(self._lib.rrv_transfer_frame_mode(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p)))
             return out
@@ -169,10 +169,11 @@ class Stylization():
         else:
             a = np.stack([_u8_image(f, "frame") for f in frames])
         B, H, W, _ = a.shape
+        oshape = (B, H // 8 * 8, W // 8 * 8, 3)
         if out is None:
-            out = np.empty((B, H, W, 3), dtype=np.float32)
-        elif out.dtype != np.float32 or out.shape != (B, H, W, 3) or not out.flags.c_contiguous:
-            raise ValueError("out must be a C-contiguous float32 array of shape %r" % ((B, H, W, 3),))
+            out = np.empty(oshape, dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != oshape or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape %r" % (oshape,))
         self._chk(self._lib.rrv_transfer_batch(self._h, a.ctypes.data_as(C.c_void_p), B, H, W, out.ctypes.data_as(C.c_void_p)))
         return out
 
@@ -270,7 +271,7 @@ class MultiStyleStylization(Stylization):
         self.compute()
 
     def transfer(self, cur_feature, style_weight=[1.], out=None):
-        H, W = cur_feature.shape[:2]
+        H, W = cur_feature.shape[0] // 8 * 8, cur_feature.shape[1] // 8 * 8
         if out is None:
             out = np.empty((H, W, 3), dtype=np.float32)
         elif out.dtype != np.float32 or out.shape != (H, W, 3) or not out.flags.c_contiguous:
@@ -283,7 +284,7 @@ class MultiStyleStylization(Stylization):
         """`transfer` for a run of cached features, one weight vector each, pipelined inside the library
         (rrv_transfer_features_batch).  Returns / fills a float32 [n][H][W][3] array."""
         n = len(features)
-        H, W = features[0].shape[:2]
+        H, W = features[0].shape[0] // 8 * 8, features[0].shape[1] // 8 * 8
         ns = len(style_weights[0])
         if out is None:
             out = np.empty((n, H, W, 3), dtype=np.float32)

@@ -319,3 +319,34 @@ def test_command_line_driver_end_to_end(tmp_path, pkg, weights):
         np.testing.assert_array_equal(got, D.to_uint8(ref[i]))
     avi = open(str(tmp_path / "v.avi"), "rb").read()
     assert avi.count(b"00dc") >= 20          # 10 chunks + 10 index entries
+
+
+@pytest.mark.parametrize("hw", [(203, 141), (77, 90), (15, 9)])
+def test_any_frame_size_floors_like_the_reference(hw, pkg, oracle, weights):
+    """The reference accepts any frame size: the three max pools floor it and transfer() returns 8*(H/8) x 8*(W/8)
+    pixels (test/style_network_global.py:271-281).  Same here, against the oracle: per-frame, batched, blended and
+    frame-mode entries."""
+    H, W = hw
+    Ho, Wo = H // 8 * 8, W // 8 * 8
+    style = pkg.synth_style(48, 40, kind="smooth", seed=21)
+    sampled = [pkg.synth_frame(i, 45, 61, kind="smooth", seed=60) for i in range(2)]
+    s, o = _prep_pair(pkg, oracle, weights, style, sampled)
+    o.set_state(s.get_state())
+    frames = [pkg.synth_frame(90 + i, H, W, kind="smooth", seed=60) for i in range(3)]
+    ref = [o.transfer(f) for f in frames]
+    assert ref[0].shape == (Ho, Wo, 3)
+    got = s.transfer(frames[0])
+    assert got.shape == (Ho, Wo, 3) and np.abs(got - ref[0]).max() <= IMG_ATOL
+    assert_pre_close(s.preclamp(Ho, Wo), o.transfer(frames[0], return_preclamp=True)[0])
+    b = s.transfer_batch(frames)
+    assert b.shape == (3, Ho, Wo, 3)
+    for k in range(3):
+        assert np.abs(b[k] - ref[k]).max() <= IMG_ATOL
+    np.testing.assert_array_equal(b[0], got)
+    s.close()
+    fm, fo = pkg.Stylization(weights, cuda=True, use_Global=False), oracle.Stylization(weights, use_Global=False)
+    for m in (fm, fo):
+        m.prepare_style(style)
+    g2 = fm.transfer(frames[1])
+    assert g2.shape == (Ho, Wo, 3) and np.abs(g2 - fo.transfer(frames[1])).max() <= IMG_ATOL
+    fm.close()
