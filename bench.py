@@ -91,12 +91,19 @@ def self_launch(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    live = list(procs)
+    while live and not rc:          # a rank that dies must not leave the others waiting in a collective
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                rc = rc or r
     if rc:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+        for p in live:
+            p.kill()
+        for p in live:
+            p.wait()
     raise SystemExit(rc)
 
 
@@ -221,6 +228,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # RRV_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a 1-GPU box (all ranks on GPU 0)
     backend = os.environ.get("RRV_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > max(1, torch.cuda.device_count()):
+        raise SystemExit("--gpus %d but only %d GPU(s) visible (one process per GPU; RRV_BENCH_BACKEND=gloo shares GPUs for a control-flow check)"
+                         % (world, torch.cuda.device_count()))
     local = local % max(1, torch.cuda.device_count())
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
