@@ -62,13 +62,17 @@ def rocprof_name(kernel):
     return kernel
 
 
-def measured_traffic(kernel, size=512):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/hbm_traffic.json: 512x512, 8 frames per
-    launch), or None (other sizes have no committed pass)."""
-    if size != 512:
-        return None
+def traffic_file(size, multistyle=0):
+    """The committed PMC pass of this configuration (tools/profile_round.sh -> profiles/hbm_traffic_<cfg>.json)."""
+    cfg = ("ms%d" % multistyle) if multistyle else str(size)
+    return os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % cfg)
+
+
+def measured_traffic(kernel, size=512, multistyle=0):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same
+    configuration (PMC counters cannot be collected inside the timed run), or None when no pass is committed."""
     try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+        with open(traffic_file(size, multistyle)) as f:
             t = json.load(f)
         name = rocprof_name(kernel)
         for k, v in t["kernels"].items():
@@ -77,6 +81,32 @@ def measured_traffic(kernel, size=512):
         return None
     except Exception:
         return None
+
+
+def pin_to_gpu_numa_node(local):
+    """Pin this rank's host threads to the NUMA node of its GPU (PCI bus id -> /sys/bus/pci/devices/*/numa_node): the
+    staging copies and the launch thread stay next to the GPU's root complex.  Returns a short description."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return "gpu %s: no NUMA node reported" % bdf
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            txt = f.read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return "gpu %s: node %d has no allowed cpus" % (bdf, node)
+        os.sched_setaffinity(0, cpus)
+        return "gpu %s -> NUMA node %d (%d cpus)" % (bdf, node, len(cpus))
+    except Exception as e:       # containers without sysfs PCI topology: stay unpinned
+        return "unpinned (%s)" % (type(e).__name__,)
 
 
 def self_launch(args):
@@ -107,7 +137,7 @@ def self_launch(args):
     raise SystemExit(rc)
 
 
-def roofline_and_kernels(rows, nprof, frames_per_step, size):
+def roofline_and_kernels(rows, nprof, frames_per_step, size, multistyle=0):
     """Per-kernel aggregation of the live HIP-event rows of the profiled steps and the roofline of the dominant one.
     `frac` = EXECUTED FLOPs / event time / fp32-MFMA peak (what the matrix pipe actually issues); the reference's
     direct-convolution FLOPs over the same time is `algorithmic_tflops` (the transform-domain kernels need 2.25x /
@@ -143,9 +173,9 @@ def roofline_and_kernels(rows, nprof, frames_per_step, size):
     mf = [a for nm, a in agg.items() if nm.startswith(("conv_mfma", "conv_wino", "conv_upw"))]
     roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": measured_traffic(dom[0], size),
-            "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 8 frames per "
-                              "launch; bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024)",
+            "traffic": measured_traffic(dom[0], size, multistyle),
+            "traffic_source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration; "
+                              "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024)" % os.path.basename(traffic_file(size, multistyle)),
             "algorithmic_bytes_per_launch": round(by / n),
             "algorithmic_tflops": round(fl / t_ms / 1e9, 2), "algorithmic_speedup": round(fl / fx, 3),
             "note": "achieved/frac = FLOPs the kernel EXECUTES / HIP-event time / fp32-MFMA peak; algorithmic_tflops = FLOPs of "
@@ -155,6 +185,33 @@ def roofline_and_kernels(rows, nprof, frames_per_step, size):
             "all_matrix_kernels_executed_frac": round(sum(a[4] for a in mf) / sum(a[1] for a in mf) / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
             "all_matrix_kernels_algorithmic_tflops": round(sum(a[2] for a in mf) / sum(a[1] for a in mf) / 1e9, 2)}
     return roof, kern, layers
+
+
+def c_abi_broadcast_check(model, dist, rank, world, n_styles, timeout_s=90.0):
+    """rrv_comm_unique_id (rank 0) -> the 128 bytes over the process group -> rrv_comm_init_rank -> rrv_broadcast_state
+    per style -> every rank compares its state before / after bit for bit.  Runs in a watchdog thread: a communicator
+    that never forms must not hang the bench."""
+    import threading
+    res = {}
+
+    def work():
+        try:
+            before = [model.get_state(k).copy() for k in range(n_styles)]
+            ids = [model.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = model.comm_init_rank(ids[0], world, rank)
+            for k in range(n_styles):
+                model.broadcast_state(comm, 0, rank, k)
+            same = all(np.array_equal(model.get_state(k), before[k]) for k in range(n_styles))
+            model.comm_destroy(comm)
+            res["v"] = "ok: %d style blob(s) over ncclBroadcast, %d rank(s), state %s" % (n_styles, world, "bit-identical" if same else "DIFFERS")
+        except Exception as e:
+            res["v"] = "error: %s" % (str(e)[:200],)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    return res.get("v", "timeout after %.0f s" % timeout_s)
 
 
 def cpu_baseline(setup, unit, what, budget_s=25.0):
@@ -234,12 +291,17 @@ def main():
     local = local % max(1, torch.cuda.device_count())
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if world > 1:
+    # RRV_BENCH_FORCE_DIST=1: run the process-group code path (init, barrier, broadcast, all_reduce, gather) at world size 1
+    # too, so that the RCCL branch executes on a one-GPU box (RCCL works with a single rank)
+    use_dist = world > 1 or os.environ.get("RRV_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     torch.cuda.set_device(local)
+    affinity = pin_to_gpu_numa_node(local) if os.environ.get("RRV_BENCH_NO_PIN") != "1" else "unpinned (RRV_BENCH_NO_PIN)"
     dev = torch.device("cuda", local)
     cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective payloads live
 
@@ -256,7 +318,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     if NS:
@@ -297,7 +359,7 @@ def main():
             model.compute()
             blob.copy_(torch.from_numpy(model.get_state()))
     prep_s = time.time() - t0
-    if world > 1:
+    if use_dist:
         dist.broadcast(blob, src=0)
         if rank != 0:
             b = blob.cpu().numpy()
@@ -338,13 +400,23 @@ def main():
     model.sync()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    per_rank_s = [dt]
+    if use_dist:
+        mine = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                       # each rank's own wall time (a straggler shows up here)
+        per_rank_s = [float(x.item()) for x in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the one collective of the path once more through the C ABI (rrv_broadcast_state: ncclBroadcast on an ncclComm_t
+    # built from a unique id that travels over the process group), checked bit for bit against the state every rank holds
+    c_abi_bcast = None
+    if use_dist and backend == "nccl" and os.environ.get("RRV_BENCH_NO_CABI_BCAST") != "1":
+        c_abi_bcast = c_abi_broadcast_check(model, dist, rank, world, max(1, NS))
 
     if rank == 0:
-        roof, kern, layers = roofline_and_kernels(rows, nprof, B, S)
+        roof, kern, layers = roofline_and_kernels(rows, nprof, B, S, NS)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             blobs = [model.get_state(k) for k in range(max(1, NS))]
@@ -380,6 +452,11 @@ def main():
                           "parallelism": "frame-shard x%d" % world},
                "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu,
                "prep_seconds_rank0": round(prep_s, 3), "kernels": kern}
+        # diagnostics of a multi-rank run (the driver computes scaling efficiency itself from the per-N `value`s)
+        rates = [args.steps * B / t for t in per_rank_s]
+        out["per_rank"] = {"frames_per_s": [round(r, 1) for r in rates], "min": round(min(rates), 1), "max": round(max(rates), 1),
+                           "slowest_rank": int(np.argmin(rates)), "process_group": (backend if use_dist else None),
+                           "rank0_affinity": affinity, "c_abi_rccl_broadcast": c_abi_bcast}
         if NS:
             out["feature_cache_frames_per_s"] = round(len(feats) / cache_s, 1)
         if world == 1 and not args.no_extras and not NS:
@@ -441,7 +518,7 @@ def main():
                              for k, v in sorted(layers.items(), key=lambda kv: -kv[1][1])]
         print(json.dumps(out), flush=True)
     model.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

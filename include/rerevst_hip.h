@@ -29,8 +29,9 @@ enum {
     RRV_E_HIP = -2,        /* HIP runtime error */
     RRV_E_WEIGHTS = -3,    /* unknown key, wrong shape, or weights incomplete */
     RRV_E_STATE = -4,      /* transfer before compute()/set_state, compute with no frames, ... */
-    RRV_E_NOMEM = -5,
-    RRV_E_DEBUG = -6       /* bounds-checked debug mode found a store outside a tensor's valid region */
+    RRV_E_NOMEM = -5,      /* out of device (or page-locked host) memory */
+    RRV_E_DEBUG = -6,      /* bounds-checked debug mode found a store outside a tensor's valid region */
+    RRV_E_COMM = -7        /* RCCL: library not found, or a communicator / collective call failed */
 };
 
 /* Floats in the per-style shared-state blob: 11 norm layers x {mean,rstd,lo,hi}[C]
@@ -86,6 +87,18 @@ int rrv_last_compute_info(rrv_handle h, int* groups, int* group_size, size_t* wo
 int rrv_get_state(rrv_handle h, float* out, int n, int style_id);
 int rrv_set_state(rrv_handle h, const float* in, int n, int style_id);
 
+/* Multi-GPU (one process and one handle per GPU; the reference has no distributed code — SURVEY 8(e)): frames are
+ * independent once the saved state exists, so the only collective is ONE ncclBroadcast of the blob per style and video,
+ * from the rank that ran prepare_style / add / compute.  rrv_broadcast_state issues it on the handle's stream over an
+ * ordinary ncclComm_t (pass the application's own, e.g. MPI- or torch-built, as void*); on the other ranks the style
+ * then is exactly as after rrv_set_state.  librccl.so is opened on first use (RRV_RCCL_PATH overrides the search).
+ * The three rrv_comm_* helpers build a communicator for callers without RCCL bindings (ctypes, cgo, JNI): rank 0 calls
+ * rrv_comm_unique_id, ships the 128 bytes to the others by any means, every rank calls rrv_comm_init_rank. */
+int rrv_comm_unique_id(char id[128]);
+int rrv_comm_init_rank(rrv_handle h, const char id[128], int nranks, int rank, void** comm);
+int rrv_comm_destroy(void* comm);
+int rrv_broadcast_state(rrv_handle h, void* comm, int root, int my_rank, int style_id);
+
 /* Stylization.transfer (test/framework.py:106-118): uint8 BGR HWC [H][W][3] in host
  * memory -> float32 BGR HWC [H][W][3] in 0..255 in host memory (includes the H2D / D2H crossings of
  * framework.py:109 `.to(device)` and :40 `.cpu()`).  Any H, W >= 8: as in the reference the three max pools floor the
@@ -94,6 +107,15 @@ int rrv_set_state(rrv_handle h, const float* in, int n, int style_id);
  * other transfer entry (batch, device, blend, features, frame mode).  Page-locked caller buffers (rrv_host_alloc / rrv_host_register)
  * are DMA'd directly; pageable ones are staged through the library's own pinned buffers. */
 int rrv_transfer(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* out_bgr);
+
+/* Look-ahead form of rrv_transfer for a one-frame-per-call driver loop (test/generate_real_video.py:152-171 calls
+ * framework.transfer once per frame): rrv_transfer_async queues the frame's H2D copy, kernels and D2H copy and returns
+ * a ticket at once; rrv_transfer_wait(ticket) blocks until `out_bgr` of that call is filled.  Submitting frame i+1
+ * before waiting for frame i overlaps its copy-in and kernels with frame i's kernel tails and copy-out.  Up to four
+ * tickets may be open (a fifth submission first completes the oldest).  `frame_bgr` may be reused as soon as the call
+ * returns; `out_bgr` must stay valid until its ticket is waited for.  Bit-identical to rrv_transfer. */
+int rrv_transfer_async(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* out_bgr, long* ticket);
+int rrv_transfer_wait(rrv_handle h, long ticket);
 
 /* Same computation on device-resident buffers (HBM in, HBM out), asynchronous on the
  * handle's own (non-blocking) streams; rrv_sync() waits.
@@ -141,6 +163,14 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* style_weigh
  * two (stream, workspace, blended-state) sets and the D2H copy of one frame overlaps the next frame's kernels. */
 int rrv_transfer_features_batch(rrv_handle h, const int* feature_ids, const float* style_weight, int n, int n_styles, float* out_bgr);
 int rrv_release_features(rrv_handle h);
+/* Capacity policy of the feature cache (default 64 GiB).  The reference spills every frame's feature to disk
+ * (test.py:87-101, cache/%d.pt), so its video length is unbounded; here a cached feature costs 42 MB of HBM per
+ * 1152x1152 frame.  Once the cache would exceed `bytes`, rrv_generate_content_features keeps the frame's uint8 pixels
+ * instead (a tenth of the size) and every use of that feature re-runs the encoder first (rrv_transfer_features[_batch]
+ * = encoder + blended decoder, rrv_add_patch encodes on the spot) — slower, never an out-of-memory error.
+ * rrv_feature_cache_info: cached features, spilled ones, bytes held by the cached ones. */
+int rrv_set_feature_cache_cap(rrv_handle h, size_t bytes);
+int rrv_feature_cache_info(rrv_handle h, int* resident, int* spilled, size_t* bytes);
 
 /* Stylization(checkpoint, cuda, use_Global=False).transfer (test/framework.py:69-72,106-118 with
  * test/style_network_frame.py): per-frame InstanceNorm statistics (:39-43) and per-frame filter
@@ -180,6 +210,10 @@ int rrv_host_unregister(void* p);
  * store and returns RRV_OK only if the checker reports both. */
 int rrv_set_debug(rrv_handle h, int level);
 int rrv_debug_selftest(rrv_handle h);
+/* Failure injection: the nth next device allocation of this handle (1 = the very next one) reports out-of-memory
+ * (RRV_E_NOMEM, as a real hipErrorOutOfMemory does); 0 disarms.  Workspaces are built transactionally — complete or
+ * released — so the call after a failed one starts over instead of finding a half-built plan. */
+int rrv_debug_fail_alloc(rrv_handle h, int nth);
 
 /* Per-launch timing with HIP events recorded on the handle's own stream.
  * rrv_profile_begin() clears the log and starts bracketing every kernel launch with

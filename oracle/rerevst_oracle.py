@@ -42,6 +42,18 @@ assert STATE_FLOATS == 17536
 
 # ---- primitive operators ---------------------------------------------------------------
 
+F64 = np.float64
+
+
+def _mean32(a, **kw):
+    """Mean with a float64 accumulator, rounded once to float32.  numpy's float32 reduction over the leading axes adds
+    rows one after the other (error ~ N * 6e-8 relative: 7e-6 on a CONSTANT channel over 27 648 pixels), torch's
+    cascaded sums are accurate to an ulp; after `InstanceNorm.compute`'s rsqrt(var + 1e-8) such an error is multiplied
+    by up to 1e4 (tests/golden/global_a_dead).  The correctly rounded mean is what the reference's own arithmetic
+    approximates."""
+    return np.mean(a, dtype=F64, **kw).astype(F32)
+
+
 # "numpy": nine shifted GEMMs (the default; what the parity tests use).  "torch": the same convolution through
 # torch.nn.functional.conv2d on the CPU — the primitive the reference itself calls (nn.Conv2d -> oneDNN) — used by
 # bench.py's cpu_baseline leg so that the CPU column is timed on the reference's own arithmetic library.
@@ -172,8 +184,8 @@ class Net:
             if idx in STYLE_TAP_AFTER:
                 C = x.shape[-1]
                 flat = x.reshape(-1, C)
-                var = flat.var(axis=0, ddof=1, dtype=F32) + F32(1e-5)
-                feats[STYLE_TAP_AFTER[idx]] = (flat.mean(axis=0, dtype=F32), np.sqrt(var).astype(F32))
+                var = flat.var(axis=0, ddof=1, dtype=F64).astype(F32) + F32(1e-5)
+                feats[STYLE_TAP_AFTER[idx]] = (_mean32(flat, axis=0), np.sqrt(var).astype(F32))
             if idx in POOL_AFTER:
                 x = maxpool2(x)
         feats["map"] = x
@@ -191,9 +203,9 @@ class NormState:
         rsqrt; min/max of the normalised batch (quirks Q3, Q4)."""
         C = x.shape[-1]
         flat = x.reshape(-1, C)
-        self.mean = flat.mean(axis=0, dtype=F32)
+        self.mean = _mean32(flat, axis=0)
         xc = flat - self.mean
-        self.rstd = (F32(1) / np.sqrt((xc * xc).mean(axis=0, dtype=F32) + eps)).astype(F32)
+        self.rstd = (F32(1) / np.sqrt(_mean32(xc * xc, axis=0) + eps)).astype(F32)
         xn = xc * self.rstd
         self.hi = xn.max(axis=0)
         self.lo = xn.min(axis=0)
@@ -237,9 +249,9 @@ class Decoder:
         `style` the normalised style map; FC is a plain nn.Linear (no activation)."""
         p = name + "."
         c = conv3x3(content, self._w(p + "down_sample.0.weight"), self._w(p + "down_sample.0.bias"))
-        c = c.reshape(c.shape[0], -1, c.shape[-1]).mean(axis=1, dtype=F32).mean(axis=0, dtype=F32)
+        c = _mean32(_mean32(c.reshape(c.shape[0], -1, c.shape[-1]), axis=1), axis=0)
         s = conv3x3(style, self._w(p + "down_sample.0.weight"), self._w(p + "down_sample.0.bias"))
-        s = s.reshape(-1, s.shape[-1]).mean(axis=0, dtype=F32)
+        s = _mean32(s.reshape(-1, s.shape[-1]), axis=0)
         v = np.concatenate([c, s]).astype(F32)
         f = self._w(p + "FC.weight") @ v + self._w(p + "FC.bias")
         return f.reshape(32, 32).astype(F32)
@@ -296,9 +308,9 @@ class Decoder:
 def inorm_frame(x, eps=F32(1e-8)):
     """InstanceNorm.forward of the frame-mode network (test/style_network_frame.py:39-43): per-image,
     per-channel over (H,W), biased, rsqrt; no saved state, no clamp."""
-    m = x.mean(axis=(1, 2), keepdims=True, dtype=F32)
+    m = _mean32(x, axis=(1, 2), keepdims=True)
     xc = x - m
-    r = (F32(1) / np.sqrt((xc * xc).mean(axis=(1, 2), keepdims=True, dtype=F32) + eps)).astype(F32)
+    r = (F32(1) / np.sqrt(_mean32(xc * xc, axis=(1, 2), keepdims=True) + eps)).astype(F32)
     return xc * r
 
 
@@ -316,9 +328,9 @@ class FrameDecoder:
         """FilterPredictor.forward (style_network_frame.py:53-62)."""
         p = name + "."
         c = conv3x3(content, self._w(p + "down_sample.0.weight"), self._w(p + "down_sample.0.bias"))
-        c = c.reshape(-1, c.shape[-1]).mean(axis=0, dtype=F32)
+        c = _mean32(c.reshape(-1, c.shape[-1]), axis=0)
         s = conv3x3(style, self._w(p + "down_sample.0.weight"), self._w(p + "down_sample.0.bias"))
-        s = s.reshape(-1, s.shape[-1]).mean(axis=0, dtype=F32)
+        s = _mean32(s.reshape(-1, s.shape[-1]), axis=0)
         f = self._w(p + "FC.weight") @ np.concatenate([c, s]).astype(F32) + self._w(p + "FC.bias")
         return f.reshape(32, 32).astype(F32)
 

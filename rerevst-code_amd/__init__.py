@@ -5,7 +5,7 @@ plus this thin host-side mirror of the reference's ``Stylization`` interface
 (test/framework.py:56-118).  Importing the package is cheap; constructing ``Stylization``
 loads the HIP library and fails loudly if it is missing.
 """
-from .weights import weight_table, synthetic_weights, load_checkpoint  # noqa: F401
+from .weights import weight_table, synthetic_weights, weight_variant, load_checkpoint  # noqa: F401
 from .synth import synth_frame, synth_style  # noqa: F401
 
 

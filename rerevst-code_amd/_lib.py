@@ -29,7 +29,13 @@ SYMBOLS = {
     "rrv_last_compute_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "rrv_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "rrv_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rrv_comm_init_rank": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rrv_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rrv_broadcast_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rrv_transfer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rrv_transfer_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_long)]),
+    "rrv_transfer_wait": (C.c_int, [C.c_void_p, C.c_long]),
     "rrv_transfer_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rrv_transfer_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rrv_transfer_blend_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
@@ -42,6 +48,8 @@ SYMBOLS = {
     "rrv_transfer_features": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "rrv_transfer_features_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     "rrv_release_features": (C.c_int, [C.c_void_p]),
+    "rrv_set_feature_cache_cap": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rrv_feature_cache_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "rrv_transfer_frame_mode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rrv_get_preclamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rrv_sync": (C.c_int, [C.c_void_p]),
@@ -53,6 +61,7 @@ SYMBOLS = {
     "rrv_host_unregister": (C.c_int, [C.c_void_p]),
     "rrv_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_debug_selftest": (C.c_int, [C.c_void_p]),
+    "rrv_debug_fail_alloc": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_profile_begin": (C.c_int, [C.c_void_p]),
     "rrv_profile_end": (C.c_int, [C.c_void_p]),
     "rrv_profile_count": (C.c_int, [C.c_void_p]),
@@ -73,9 +82,14 @@ def _share_torch_hip_runtime():
         import importlib.util
         spec = importlib.util.find_spec("torch")
         if spec and spec.submodule_search_locations:
-            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+            cand = os.path.join(libdir, "libamdhip64.so")
             if os.path.exists(cand):
                 C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            # rrv_broadcast_state dlopens RCCL lazily: point it at the copy built against the same HIP runtime
+            rccl = os.path.join(libdir, "librccl.so")
+            if os.path.exists(rccl):
+                os.environ.setdefault("RRV_RCCL_PATH", rccl)
     except Exception:
         pass
 

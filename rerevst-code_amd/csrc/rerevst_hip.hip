@@ -3,6 +3,7 @@
 // (Stylization.transfer, test/framework.py:106-118) and the preparation passes
 // (prepare_style / add / compute, test/framework.py:82-104).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <string.h>
 #include <thread>
@@ -63,10 +64,12 @@ const int STYLE_SLICE[9] = {1, 2, 2, 3, 3, 4, 4, 4, 4};
 
 struct EncPlan {   // encoder activations for one (B, H, W)
     int B = 0, H = 0, W = 0;
+    unsigned stamp = 0;     // last use (two geometries per slot, least recently used one is replaced)
     Tens c11, p1, c21, p2, c31, c32, c33, p3, c41;
 };
 struct DecPlan {   // per-frame decoder activations for one (B, H, W) of the FRAME batch
     int B = 0, H = 0, W = 0;
+    unsigned stamp = 0;
     Tens d, f1, f2, f3, xs4, a4, o4, xs3, a3, o3, xs2, a2, o2;
     Tens dpart;             // [.., 32 * split]: partial sums of the split-K 512->32 KernelFilter convolution (allocated on first use)
     float* pre = nullptr;   // [H][W][3] pre-clamp tap
@@ -114,10 +117,17 @@ struct rrv_ctx {
     float* fold_tmp = nullptr;                 // OIHW scratch for folds (512*32*9 floats)
     StyleState styles[RRV_MAX_STYLES];
     int active_src = -1;                       // style id whose state is folded (-2: blend)
-    EncPlan enc_frame[RRV_MAX_SLOTS], enc_add, enc_style;
-    DecPlan dec[RRV_MAX_SLOTS];
-    struct Feature { float* p; int H, W; };    // cached raw relu4_1 feature of one (padded) frame, H x W = frame size
+    // Two workspace geometries per slot: a caller alternating between two frame sizes (e.g. a video and its preview)
+    // keeps both resident instead of re-allocating ~0.76 GB per call; a third size replaces the least recently used.
+    EncPlan enc_frame[RRV_MAX_SLOTS][2], enc_add, enc_style;
+    DecPlan dec[RRV_MAX_SLOTS][2];
+    unsigned plan_clock = 0;
+    // cached raw relu4_1 feature of one (padded) frame, H x W = frame size.  Beyond feat_cap (rrv_set_feature_cache_cap)
+    // a frame is kept as its uint8 pixels instead (u8, ~10x smaller) and re-encoded when it is used: the reference's
+    // cache is on disk and unbounded (test.py:87-101), this one degrades to "encode + decode per frame" instead of failing
+    struct Feature { float* p; int H, W; uint8_t* u8; };
     std::vector<Feature> features;
+    size_t feat_cap = (size_t)64 << 30, feat_bytes = 0;
     std::vector<float*> patches;               // relu4_1 features of added frames (ring layout images)
     int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
     uint8_t* d_u8 = nullptr; size_t d_u8_cap = 0;
@@ -140,8 +150,13 @@ struct rrv_ctx {
     struct HostStage { uint8_t* pin_in = nullptr; float* pin_out = nullptr; uint8_t* d_in = nullptr; float* d_out = nullptr;
                        size_t cap = 0, pcap = 0; hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr; } hstage[4];
     hipStream_t copy_in = nullptr, copy_out = nullptr;
+    // rrv_transfer_async: ticket t lives in staging set t % 4 until rrv_transfer_wait(t) (or a later submission that needs
+    // its set) retires it; `out` / `out_bytes` = where a pageable caller buffer still has to be filled from pin_out
+    struct Ticket { long id = -1; float* out = nullptr; size_t out_bytes = 0; bool open = false; } tickets[4];
+    long next_ticket = 0;
     int n_cus = 256;
     int debug = 0;                    // rrv_set_debug / RRV_DEBUG: 1 = sync + check after every API call, 2 = after every kernel launch
+    int fail_alloc_in = 0;            // rrv_debug_fail_alloc: the n-th next device allocation reports out-of-memory
     bool profiling = false;
     std::vector<ProfEntry> prof;
 };
@@ -155,12 +170,13 @@ namespace {
             char _b[512];                                                                         \
             snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
             h->err = _b;                                                                          \
-            return RRV_E_HIP;                                                                     \
+            return _e == hipErrorOutOfMemory ? RRV_E_NOMEM : RRV_E_HIP;                           \
         }                                                                                         \
     } while (0)
 #define RCHK(expr) do { int _r = (expr); if (_r != RRV_OK) return _r; } while (0)
 
 int fail(rrv_handle h, int code, const std::string& msg) { h->err = msg; return code; }
+int dmalloc(rrv_handle h, void** p, size_t bytes);
 
 int sync_all(rrv_handle h) {
     for (int i = 0; i < RRV_MAX_SLOTS; ++i)
@@ -170,8 +186,29 @@ int sync_all(rrv_handle h) {
     return RRV_OK;
 }
 
+// Every device allocation of a handle goes through here: device out-of-memory is RRV_E_NOMEM (not a generic HIP
+// error), and the debug hook rrv_debug_fail_alloc makes the n-th next allocation fail that way (tests of the
+// failure paths: a half-built workspace must never be used).
+int dmalloc(rrv_handle h, void** p, size_t bytes) {
+    *p = nullptr;
+    if (h->fail_alloc_in > 0 && --h->fail_alloc_in == 0) {
+        char b[160];
+        snprintf(b, sizeof b, "out of device memory (injected by rrv_debug_fail_alloc) allocating %zu bytes", bytes);
+        return fail(h, RRV_E_NOMEM, b);
+    }
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        char b[200];
+        snprintf(b, sizeof b, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return fail(h, e == hipErrorOutOfMemory ? RRV_E_NOMEM : RRV_E_HIP, b);
+    }
+    return RRV_OK;
+}
+
 int dalloc(rrv_handle h, float** p, size_t floats, bool zero = true) {
-    HIPCHK(hipMalloc((void**)p, floats * sizeof(float)));
+    RCHK(dmalloc(h, (void**)p, floats * sizeof(float)));
     if (zero) HIPCHK(hipMemsetAsync(*p, 0, floats * sizeof(float), h->stream));
     return RRV_OK;
 }
@@ -225,7 +262,7 @@ int debug_verify(rrv_handle h, const char* where) {
     }
     if (recs.empty()) return RRV_OK;
     unsigned* d_cnt = nullptr;
-    HIPCHK(hipMalloc((void**)&d_cnt, recs.size() * 2 * sizeof(unsigned)));
+    RCHK(dmalloc(h, (void**)&d_cnt, recs.size() * 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(d_cnt, 0, recs.size() * 2 * sizeof(unsigned)));
     for (size_t i = 0; i < recs.size(); ++i)
         hipLaunchKernelGGL(dbg_check_k, dim3(64), dim3(256), 0, h->streams[0], (const float*)recs[i].base, (const float*)ptrs[i], recs[i].B, recs[i].H, recs[i].W,
@@ -260,7 +297,7 @@ int talloc(rrv_handle h, Tens* t, int B, int H, int W, int C) {
     const size_t slack = (size_t)20 * (W + 2 + 20) * C;
     const size_t floats = (size_t)B * t->img_floats() + slack;
     if (!h->debug) return dalloc(h, &t->p, floats, true);
-    HIPCHK(hipMalloc((void**)&t->base, (floats + 2 * DBG_GUARD) * sizeof(float)));
+    RCHK(dmalloc(h, (void**)&t->base, (floats + 2 * DBG_GUARD) * sizeof(float)));
     t->p = t->base + DBG_GUARD;
     hipLaunchKernelGGL(dbg_fill_k, dim3(16), dim3(256), 0, h->stream, (uint32_t*)t->base, DBG_GUARD, DBG_CANARY);
     hipLaunchKernelGGL(dbg_fill_k, dim3(16), dim3(256), 0, h->stream, (uint32_t*)(t->p + floats), DBG_GUARD, DBG_CANARY);
@@ -317,8 +354,8 @@ struct ConvKey { int BN, TAPS, UPS, EPI; ConvFn fn; const char* name; AttrFn att
 const ConvKey CONV_TABLE[] = {
     // 1x1 shortcuts of the residual blocks (evaluated before the upsample)
     CK(128, 1, 0, 0), CK(64, 1, 0, 0),
-    // preparation pass: FilterPredictor 512->32 convs and the 32->512 conv of frame 0 (raw outputs)
-    CK(32, 9, 0, 0), CK(128, 9, 0, 0),
+    // preparation pass: FilterPredictor 512->32 convs (raw outputs)
+    CK(32, 9, 0, 0),
 };
 
 constexpr int WINO_NW = 8;     // waves per Winograd workgroup (conv_wino.h: 8 = two waves per SIMD, one 16-cout block each)
@@ -505,8 +542,8 @@ int chan_stats(rrv_handle h, const Tens& t, int mode, float* out) {
     if (nblk < 1) nblk = 1;
     const int ppb = (int)((npix + nblk - 1) / nblk);
     // scratch shared by all calls: they are ordered on h->stream (1024 partial blocks x 3 x 512 channels at most)
-    if (!h->stat_part) HIPCHK(hipMalloc((void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
-    if (!h->stat_mean) HIPCHK(hipMalloc((void**)&h->stat_mean, 512 * sizeof(float)));
+    if (!h->stat_part) RCHK(dmalloc(h, (void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
+    if (!h->stat_mean) RCHK(dmalloc(h, (void**)&h->stat_mean, 512 * sizeof(float)));
     if (t.C > 512) return fail(h, RRV_E_ARG, "chan_stats: more than 512 channels");
     double* part = h->stat_part;
     float* mean = h->stat_mean;
@@ -544,7 +581,9 @@ int pointwise(rrv_handle h, const Tens& x, Tens& y, const float* mean, const flo
 }
 
 // ---- folded KernelFilter weights for a state blob ------------------------------------------
-int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/, bool direct = true /* also the direct-form packs (compute()'s raw 32->512 conv) */) {
+// (both folded layers run the row-split transform-domain kernel everywhere — per-frame path and compute()'s frame-0
+// residual alike — so only the Winograd packs are built)
+int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
     char pre[64];
     snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
     const ConvW& wd = h->conv[std::string(pre) + ".down_sample.0"];
@@ -556,11 +595,9 @@ int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/, bool direct = 
     hipLaunchKernelGGL(fold_down_k, dim3((32 * 512 * 9 + 255) / 256), dim3(256), 0, h->stream, F1, (const float*)wd.raw,
                        (const float*)wd.bias, fd.raw, fd.bias, 512 * 9);
     HIPCHK(hipGetLastError());
-    if (direct) RCHK(pack(h, fd));
     RCHK(pack_wino(h, fd));          // 512->32 is one Winograd cout slab
     hipLaunchKernelGGL(fold_up_k, dim3((512 * 32 * 9 + 255) / 256), dim3(256), 0, h->stream, F2, (const float*)wu.raw, fu.raw, 512);
     HIPCHK(hipGetLastError());
-    if (direct) RCHK(pack(h, fu));
     RCHK(pack_wino(h, fu));          // 32 input channels = two 16-channel chunks per work item
     return RRV_OK;
 }
@@ -592,21 +629,46 @@ int ensure_active(rrv_handle h) {
 }
 
 // ---- encoder ----------------------------------------------------------------------------
+void enc_free(EncPlan& e) {
+    for (Tens* t : {&e.c11, &e.p1, &e.c21, &e.p2, &e.c31, &e.c32, &e.c33, &e.p3, &e.c41}) tfree(t);
+    e.B = e.H = e.W = 0;
+}
+// A plan is either complete or empty: the geometry is recorded only after every tensor exists; a failed allocation
+// releases what was built so far, and the next call with the same geometry starts over (it must never find a
+// half-built plan that passes the cache test and launch kernels on null tensors).
 int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {      // grow-only in B: a plan made for more images serves fewer
-    if (e.B >= B && e.H == H && e.W == W && e.c11.p) return RRV_OK;
+    if (e.B >= B && e.H == H && e.W == W && e.c41.p) return RRV_OK;
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "image too large ((H+2)*(W+2)*64 must be < 2^31)");
-    e.B = B; e.H = H; e.W = W;
+    enc_free(e);
     const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
-    RCHK(talloc(h, &e.c11, B, H, W, 64));
-    RCHK(talloc(h, &e.p1, B, H2, W2, 64));
-    RCHK(talloc(h, &e.c21, B, H2, W2, 128));
-    RCHK(talloc(h, &e.p2, B, H4, W4, 128));
-    RCHK(talloc(h, &e.c31, B, H4, W4, 256));
-    RCHK(talloc(h, &e.c32, B, H4, W4, 256));
-    RCHK(talloc(h, &e.c33, B, H4, W4, 256));
-    RCHK(talloc(h, &e.p3, B, H8, W8, 256));
-    RCHK(talloc(h, &e.c41, B, H8, W8, 512));
+    auto build = [&]() -> int {
+        RCHK(talloc(h, &e.c11, B, H, W, 64));
+        RCHK(talloc(h, &e.p1, B, H2, W2, 64));
+        RCHK(talloc(h, &e.c21, B, H2, W2, 128));
+        RCHK(talloc(h, &e.p2, B, H4, W4, 128));
+        RCHK(talloc(h, &e.c31, B, H4, W4, 256));
+        RCHK(talloc(h, &e.c32, B, H4, W4, 256));
+        RCHK(talloc(h, &e.c33, B, H4, W4, 256));
+        RCHK(talloc(h, &e.p3, B, H8, W8, 256));
+        RCHK(talloc(h, &e.c41, B, H8, W8, 512));
+        return RRV_OK;
+    };
+    const int rc = build();
+    if (rc != RRV_OK) { enc_free(e); return rc; }
+    e.B = B; e.H = H; e.W = W;
     return RRV_OK;
+}
+
+// the plan of `slot` for (B, H, W): a resident one that fits, else the emptier / least recently used of the two
+template <class Plan>
+Plan& pick_plan(rrv_handle h, Plan (&v)[2], int B, int H, int W) {
+    int k = -1;
+    for (int i = 0; i < 2; ++i) if (v[i].H == H && v[i].W == W && v[i].B >= B) k = i;
+    if (k < 0) for (int i = 0; i < 2; ++i) if (v[i].H == H && v[i].W == W) k = i;        // same size, more images: grow it
+    if (k < 0) for (int i = 0; i < 2; ++i) if (v[i].B == 0) { k = i; break; }
+    if (k < 0) k = v[0].stamp <= v[1].stamp ? 0 : 1;
+    v[k].stamp = ++h->plan_clock;
+    return v[k];
 }
 
 // vgg19.features[0:21] on a device-resident uint8 BGR image.  which: 0 Encoder (grey), 1 EncoderStyle (colour).
@@ -645,31 +707,50 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
 int ensure_u8(rrv_handle h, size_t bytes) {
     if (h->d_u8_cap >= bytes) return RRV_OK;
     if (h->d_u8) (void)hipFree(h->d_u8);
-    HIPCHK(hipMalloc((void**)&h->d_u8, bytes));
+    RCHK(dmalloc(h, (void**)&h->d_u8, bytes));
     h->d_u8_cap = bytes;
     return RRV_OK;
 }
 
+int ensure_outf(rrv_handle h, size_t floats) {
+    if (h->d_outf_cap >= floats) return RRV_OK;
+    if (h->d_outf) (void)hipFree(h->d_outf);
+    h->d_outf = nullptr; h->d_outf_cap = 0;
+    RCHK(dmalloc(h, (void**)&h->d_outf, floats * sizeof(float)));
+    h->d_outf_cap = floats;
+    return RRV_OK;
+}
+
 // ---- per-frame decoder --------------------------------------------------------------------
-int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {
-    if (d.B >= B && d.H == H && d.W == W && d.d.p) return RRV_OK;
-    d.B = B; d.H = H; d.W = W;
+void dec_free(rrv_handle h, DecPlan& d) {
+    for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2, &d.dpart}) tfree(t);
+    if (d.pre) { if (h->last_pre == d.pre) h->last_pre = nullptr; (void)hipFree(d.pre); d.pre = nullptr; }
+    d.B = d.H = d.W = 0;
+}
+int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {       // complete or empty, as enc_plan
+    if (d.B >= B && d.H == H && d.W == W && d.pre) return RRV_OK;
+    dec_free(h, d);
     const int H8 = H / 8, W8 = W / 8, H4 = H / 4, W4 = W / 4, H2 = H / 2, W2 = W / 2;
-    RCHK(talloc(h, &d.d, B, H8, W8, 32));
-    RCHK(talloc(h, &d.f1, B, H8, W8, 512));
-    RCHK(talloc(h, &d.f2, B, H8, W8, 512));
-    RCHK(talloc(h, &d.f3, B, H8, W8, 512));
-    RCHK(talloc(h, &d.xs4, B, H8, W8, 256));
-    RCHK(talloc(h, &d.a4, B, H4, W4, 256));
-    RCHK(talloc(h, &d.o4, B, H4, W4, 256));
-    RCHK(talloc(h, &d.xs3, B, H4, W4, 128));
-    RCHK(talloc(h, &d.a3, B, H2, W2, 128));
-    RCHK(talloc(h, &d.o3, B, H2, W2, 128));
-    RCHK(talloc(h, &d.xs2, B, H2, W2, 64));
-    RCHK(talloc(h, &d.a2, B, H, W, 64));
-    RCHK(talloc(h, &d.o2, B, H, W, 64));
-    if (d.pre) { if (h->last_pre == d.pre) h->last_pre = nullptr; (void)hipFree(d.pre); }
-    RCHK(dalloc(h, &d.pre, (size_t)B * H * W * 3, true));
+    auto build = [&]() -> int {
+        RCHK(talloc(h, &d.d, B, H8, W8, 32));
+        RCHK(talloc(h, &d.f1, B, H8, W8, 512));
+        RCHK(talloc(h, &d.f2, B, H8, W8, 512));
+        RCHK(talloc(h, &d.f3, B, H8, W8, 512));
+        RCHK(talloc(h, &d.xs4, B, H8, W8, 256));
+        RCHK(talloc(h, &d.a4, B, H4, W4, 256));
+        RCHK(talloc(h, &d.o4, B, H4, W4, 256));
+        RCHK(talloc(h, &d.xs3, B, H4, W4, 128));
+        RCHK(talloc(h, &d.a3, B, H2, W2, 128));
+        RCHK(talloc(h, &d.o3, B, H2, W2, 128));
+        RCHK(talloc(h, &d.xs2, B, H2, W2, 64));
+        RCHK(talloc(h, &d.a2, B, H, W, 64));
+        RCHK(talloc(h, &d.o2, B, H, W, 64));
+        RCHK(dalloc(h, &d.pre, (size_t)B * H * W * 3, true));
+        return RRV_OK;
+    };
+    const int rc = build();
+    if (rc != RRV_OK) { dec_free(h, d); return rc; }
+    d.B = B; d.H = H; d.W = W;
     return RRV_OK;
 }
 
@@ -749,10 +830,10 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         HIPCHK(hipEventRecord(h->slot_ev[slot], h->caller_stream));
         HIPCHK(hipStreamWaitEvent(h->stream, h->slot_ev[slot], 0));
     }
-    RCHK(enc_plan(h, h->enc_frame[slot], B, H, W));
-    RCHK(dec_plan(h, h->dec[slot], B, Ho, Wo));
-    DecPlan& d = h->dec[slot];
-    EncPlan& e = h->enc_frame[slot];
+    EncPlan& e = pick_plan(h, h->enc_frame[slot], B, H, W);
+    DecPlan& d = pick_plan(h, h->dec[slot], B, Ho, Wo);
+    RCHK(enc_plan(h, e, B, H, W));
+    RCHK(dec_plan(h, d, B, Ho, Wo));
     const float* st = h->cur->active;
     if (feat) {   // cached raw relu4_1 feature: Decoder.norm[0] (saved stats + clamp) as a pointwise step
         Tens src; src.p = const_cast<float*>(feat); src.B = 1; src.H = H / 8; src.W = W / 8; src.C = 512;
@@ -813,19 +894,24 @@ int prep_plan(rrv_handle h, int B, int hh, int ww, int sH, int sW) {
     if (P.B == B && P.hh == hh && P.ww == ww && P.sH == sH && P.sW == sW && P.cn.p) return RRV_OK;
     RCHK(sync_all(h));
     prep_free(h);
+    auto build = [&]() -> int {
+        RCHK(dalloc(h, &P.cmean, 64));
+        RCHK(talloc(h, &P.cn, B, hh, ww, 512));
+        RCHK(talloc(h, &P.nxt, B, hh, ww, 512));
+        RCHK(talloc(h, &P.t32, B, hh, ww, 32));
+        RCHK(talloc(h, &P.d32, 1, hh, ww, 32));
+        RCHK(talloc(h, &P.u, 1, hh, ww, 512));
+        const int cout[3] = {256, 128, 64};
+        for (int k = 0, H = hh, W = ww; k < 3; ++k, H *= 2, W *= 2) {
+            RCHK(talloc(h, &P.xs[k], B, H, W, cout[k]));
+            RCHK(talloc(h, &P.a[k], B, 2 * H, 2 * W, cout[k]));
+            RCHK(talloc(h, &P.o[k], B, 2 * H, 2 * W, cout[k]));
+        }
+        return RRV_OK;
+    };
+    const int rc = build();
+    if (rc != RRV_OK) { prep_free(h); return rc; }      // complete or empty, as enc_plan
     P.B = B; P.hh = hh; P.ww = ww; P.sH = sH; P.sW = sW;
-    RCHK(dalloc(h, &P.cmean, 64));
-    RCHK(talloc(h, &P.cn, B, hh, ww, 512));
-    RCHK(talloc(h, &P.nxt, B, hh, ww, 512));
-    RCHK(talloc(h, &P.t32, B, hh, ww, 32));
-    RCHK(talloc(h, &P.d32, 1, hh, ww, 32));
-    RCHK(talloc(h, &P.u, 1, hh, ww, 512));
-    const int cout[3] = {256, 128, 64};
-    for (int k = 0, H = hh, W = ww; k < 3; ++k, H *= 2, W *= 2) {
-        RCHK(talloc(h, &P.xs[k], B, H, W, cout[k]));
-        RCHK(talloc(h, &P.a[k], B, 2 * H, 2 * W, cout[k]));
-        RCHK(talloc(h, &P.o[k], B, 2 * H, 2 * W, cout[k]));
-    }
     return RRV_OK;
 }
 
@@ -914,7 +1000,7 @@ int chan_stats1(rrv_handle h, const Tens& t, float* out) {
     if (nblk > 512) nblk = 512;
     if (nblk < 1) nblk = 1;
     if (t.C > 512) return fail(h, RRV_E_ARG, "chan_stats: more than 512 channels");
-    if (!h->stat_part) HIPCHK(hipMalloc((void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
+    if (!h->stat_part) RCHK(dmalloc(h, (void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
     StatP sp{t.p, t.B, t.H, t.W, t.C, nullptr, h->stat_part, 0, 0};
     RCHK(launch(h, "chan_stat1", 0, 4.0 * npix * t.C, [&] { hipLaunchKernelGGL(chan_stat1_k, dim3(nblk), dim3(256), 0, h->stream, sp); }));
     return launch(h, "chan_stat1_final", 0, 0, [&] {
@@ -927,10 +1013,10 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
     float* st = S.blob;
     h->stream = h->streams[0];
     const int Ho = H / 8 * 8, Wo = W / 8 * 8;       // any frame size, as in transfer_device
-    RCHK(enc_plan(h, h->enc_frame[0], 1, H, W));
-    RCHK(dec_plan(h, h->dec[0], 1, Ho, Wo));
-    EncPlan& e = h->enc_frame[0];
-    DecPlan& d = h->dec[0];
+    EncPlan& e = pick_plan(h, h->enc_frame[0], 1, H, W);
+    DecPlan& d = pick_plan(h, h->dec[0], 1, Ho, Wo);
+    RCHK(enc_plan(h, e, 1, H, W));
+    RCHK(dec_plan(h, d, 1, Ho, Wo));
     constexpr int RS_PARTS = 1;      // (splitting the pixels over several blocks per channel quad measured slower: the merge in pred_mean_k costs more)
     if (!h->frame_S) { RCHK(dalloc(h, &h->frame_S, RS_PARTS * 9 * 512)); RCHK(dalloc(h, &h->frame_cmean, 64)); }
     RCHK(run_encoder(h, e, d_img, 0, nullptr, nullptr, 1));
@@ -961,7 +1047,7 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
                                (const float*)(h->frame_cmean + 32 * g), (const float*)(S.smean + (2 * f + g) * 32), st + SL.filt[2 * f + g]);
             HIPCHK(hipGetLastError());
         }
-        RCHK(fold_filters(h, st, f, false));
+        RCHK(fold_filters(h, st, f));
         RCHK(filter_down(h, cur, d, f, 1));
         ConvCall u{&d.d, fo[f], &h->cur->fold_up[f], hh, ww};
         u.epi = E_RES | (f == 2 ? E_NORM2 : 0); u.res = cur;
@@ -1002,8 +1088,10 @@ int frame_mode_forward(rrv_handle h, const uint8_t* d_img, int H, int W, float* 
 // each of the 14 sync points every GROUP of G frames re-runs the decoder prefix from its relu4_1 features with the
 // statistics already known, contributes its partial (chan_merge_k) and is dropped.  Workspace = one group, whatever B.
 size_t tens_bytes(int B, int H, int W, int C) { return ((size_t)B * (H + 2) * (W + 2) * C + (size_t)20 * (W + 2 + 20) * C) * sizeof(float); }
-size_t prep_bytes(int B, int hh, int ww, int sH, int sW) {      // what prep_plan allocates (+ the [B,hh,ww,512] content batch)
+size_t prep_bytes(int B, int hh, int ww, int sH, int sW, bool streaming = false) {      // what prep_plan allocates (+ the [B,hh,ww,512] content batch)
     (void)sH; (void)sW;
+    if (streaming)       // + frame 0's copy and its three KernelFilter residuals (the group copy is the content batch below)
+        return prep_bytes(B, hh, ww, sH, sW) + 4 * tens_bytes(1, hh, ww, 512);
     size_t n = 2 * tens_bytes(B, hh, ww, 512) + tens_bytes(B, hh, ww, 32) + tens_bytes(1, hh, ww, 32) + tens_bytes(1, hh, ww, 512) + tens_bytes(B, hh, ww, 512);
     const int cout[3] = {256, 128, 64};
     for (int k = 0, H = hh, W = ww; k < 3; ++k, H *= 2, W *= 2) n += tens_bytes(B, H, W, cout[k]) + 2 * tens_bytes(B, 2 * H, 2 * W, cout[k]);
@@ -1018,10 +1106,10 @@ int chan_stats_group(rrv_handle h, const Tens& t, bool want_m2, int slot, double
     if (nblk < 1) nblk = 1;
     const int ppb = (int)((npix + nblk - 1) / nblk);
     if (t.C > 512) return fail(h, RRV_E_ARG, "chan_stats: more than 512 channels");
-    if (!h->stat_part) HIPCHK(hipMalloc((void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
-    if (!h->stat_part2) HIPCHK(hipMalloc((void**)&h->stat_part2, (size_t)1024 * 3 * 512 * sizeof(double)));
-    if (!h->stat_mean) HIPCHK(hipMalloc((void**)&h->stat_mean, 512 * sizeof(float)));
-    if (!h->stat_acc) HIPCHK(hipMalloc((void**)&h->stat_acc, (size_t)2 * 4 * 512 * sizeof(double)));
+    if (!h->stat_part) RCHK(dmalloc(h, (void**)&h->stat_part, (size_t)1024 * 3 * 512 * sizeof(double)));
+    if (!h->stat_part2) RCHK(dmalloc(h, (void**)&h->stat_part2, (size_t)1024 * 3 * 512 * sizeof(double)));
+    if (!h->stat_mean) RCHK(dmalloc(h, (void**)&h->stat_mean, 512 * sizeof(float)));
+    if (!h->stat_acc) RCHK(dmalloc(h, (void**)&h->stat_acc, (size_t)2 * 4 * 512 * sizeof(double)));
     double* acc = h->stat_acc + (size_t)slot * 4 * 512;
     StatP sp{t.p, t.B, t.H, t.W, t.C, nullptr, h->stat_part, 0, ppb};
     const int fb = (t.C + 15) / 16;
@@ -1197,14 +1285,9 @@ int rrv_create(int device, rrv_handle* out) {
 }
 
 static void free_plans(rrv_handle h) {
-    for (EncPlan* e : {&h->enc_frame[0], &h->enc_frame[1], &h->enc_frame[2], &h->enc_frame[3], &h->enc_add, &h->enc_style})
-        for (Tens* t : {&e->c11, &e->p1, &e->c21, &e->p2, &e->c31, &e->c32, &e->c33, &e->p3, &e->c41}) tfree(t);
-    for (DecPlan& d : h->dec) {
-        for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2}) tfree(t);
-        tfree(&d.dpart);
-        if (d.pre) { if (h->last_pre == d.pre) h->last_pre = nullptr; (void)hipFree(d.pre); d.pre = nullptr; }
-        d.B = d.H = d.W = 0;
-    }
+    for (auto& pair : h->enc_frame) for (EncPlan& e : pair) enc_free(e);
+    enc_free(h->enc_add); enc_free(h->enc_style);
+    for (auto& pair : h->dec) for (DecPlan& d : pair) dec_free(h, d);
     prep_free(h);
 }
 
@@ -1214,6 +1297,12 @@ int rrv_set_debug(rrv_handle h, int level) {
     RCHK(sync_all(h));
     free_plans(h);          // workspaces are re-allocated with (or without) guard bands on next use; styles keep their maps
     h->debug = level;
+    return RRV_OK;
+}
+
+int rrv_debug_fail_alloc(rrv_handle h, int nth) {
+    if (!h || nth < 0) return RRV_E_ARG;
+    h->fail_alloc_in = nth;
     return RRV_OK;
 }
 
@@ -1257,7 +1346,7 @@ int rrv_destroy(rrv_handle h) {
         if (kv.second.pk_wino) (void)hipFree(kv.second.pk_wino);
     }
     for (float* p : h->patches) (void)hipFree(p);
-    for (auto& f : h->features) if (f.p) (void)hipFree(f.p);
+    for (auto& f : h->features) { if (f.p) (void)hipFree(f.p); if (f.u8) (void)hipFree(f.u8); }
     free_plans(h);
     for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); if (s.smean) (void)hipFree(s.smean); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
@@ -1363,10 +1452,10 @@ int rrv_finalize_weights(rrv_handle h) {
         for (auto& set : h->sets) {
             ConvW& fd = set.fold_down[f];
             fd.Cout = 32; fd.Cin = 512; fd.taps = 9; fd.BN = 32;
-            RCHK(dalloc(h, &fd.raw, 32 * 512 * 9)); RCHK(dalloc(h, &fd.pk, 32 * 512 * 9)); RCHK(dalloc(h, &fd.bias, 256));   // bias[32], then zeros: the split-K slabs' bias
+            RCHK(dalloc(h, &fd.raw, 32 * 512 * 9)); RCHK(dalloc(h, &fd.bias, 256));   // bias[32], then zeros: the split-K slabs' bias
             ConvW& fu = set.fold_up[f];
             fu.Cout = 512; fu.Cin = 32; fu.taps = 9; fu.BN = 128;
-            RCHK(dalloc(h, &fu.raw, 512 * 32 * 9)); RCHK(dalloc(h, &fu.pk, 512 * 32 * 9));
+            RCHK(dalloc(h, &fu.raw, 512 * 32 * 9));
             fu.bias = h->conv[std::string(pre) + ".upsample.0"].bias;
         }
     }
@@ -1467,7 +1556,7 @@ int rrv_add(rrv_handle h, const uint8_t* frame, int H, int W) {
     if ((size_t)(h->pend_n + 1) * fb > h->pend_cap) {      // grow (x2) keeping the frames already collected
         const size_t cap = ((size_t)(h->pend_n + 1) * fb) * 2 > 16 * fb ? ((size_t)(h->pend_n + 1) * fb) * 2 : 16 * fb;
         uint8_t* nw = nullptr;
-        HIPCHK(hipMalloc((void**)&nw, cap));
+        RCHK(dmalloc(h, (void**)&nw, cap));
         if (h->pend_n) HIPCHK(hipMemcpy(nw, h->pend_u8, (size_t)h->pend_n * fb, hipMemcpyDeviceToDevice));
         if (h->pend_u8) (void)hipFree(h->pend_u8);
         h->pend_u8 = nw; h->pend_cap = cap;
@@ -1504,10 +1593,10 @@ int rrv_compute(rrv_handle h) {
         h->last_groups = 1; h->last_group_size = B; h->last_ws_bytes = prep_bytes(B, h->patch_h, h->patch_w, sH, sW);
     } else {                                                                // groups of G frames, one sync point at a time
         int G = 1;
-        while (G < B && prep_bytes(G + 1, h->patch_h, h->patch_w, sH, sW) <= h->ws_cap) ++G;
+        while (G < B && prep_bytes(G + 1, h->patch_h, h->patch_w, sH, sW, true) <= h->ws_cap) ++G;
         for (int s = 0; s < RRV_MAX_STYLES && rc == RRV_OK; ++s)
             if (h->styles[s].prepared) { rc = compute_style_streaming(h, s, G); if (first < 0) first = s; }
-        h->last_groups = (B + G - 1) / G; h->last_group_size = G; h->last_ws_bytes = prep_bytes(G, h->patch_h, h->patch_w, sH, sW);
+        h->last_groups = (B + G - 1) / G; h->last_group_size = G; h->last_ws_bytes = prep_bytes(G, h->patch_h, h->patch_w, sH, sW, true);
     }
     if (rc != RRV_OK) return rc;
     if (h->debug) RCHK(debug_verify(h, "compute"));
@@ -1534,7 +1623,95 @@ int rrv_set_state(rrv_handle h, const float* in, int n, int sid) {
     RCHK(sync_all(h));
     HIPCHK(hipMemcpy(S.blob, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     S.computed = true;
-    if (h->active_src == sid || h->active_src == -1) { h->active_src = -1; RCHK(activate_state(h, sid)); }
+    // the style set last is the one the plain transfer entries use next: re-fold now unless another style's folded
+    // state is live (after a blend, -2, nothing of the old fold is worth keeping either)
+    if (h->active_src == sid || h->active_src < 0) { h->active_src = -1; RCHK(activate_state(h, sid)); }
+    return RRV_OK;
+}
+
+// ---- RCCL from the C ABI: the one collective of the path --------------------------------------------
+// After compute() on the root rank every rank needs the 17 536-float state of each style; frames are independent from
+// there on.  librccl is opened lazily (no link-time dependency: a single-GPU user never loads it).  The communicator is
+// an ordinary ncclComm_t: pass one the application already has (e.g. built with MPI / torch), or build one with the
+// three helpers below — the 128-byte unique id travels between processes by whatever means the caller has.
+namespace {
+struct Rccl {
+    struct UId { char b[128]; };      // ncclUniqueId (passed by value)
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, UId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+typedef decltype(Rccl::CommInitRank) rccl_init_fn;
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+const char* rccl_load() {      // nullptr on success, else what went wrong
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return nullptr;
+    void* l = nullptr;
+    if (const char* e = getenv("RRV_RCCL_PATH")) l = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    for (const char* n : {"librccl.so.1", "librccl.so"})
+        if (!l) l = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);          // a copy the process already has (torch's)
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+        if (!l) l = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!l) return "librccl.so not found (set RRV_RCCL_PATH)";
+    Rccl r;
+    r.lib = l;
+    r.GetUniqueId = (int (*)(void*))dlsym(l, "ncclGetUniqueId");
+    r.CommInitRank = (rccl_init_fn)dlsym(l, "ncclCommInitRank");
+    r.CommDestroy = (int (*)(void*))dlsym(l, "ncclCommDestroy");
+    r.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(l, "ncclBroadcast");
+    r.GetErrorString = (const char* (*)(int))dlsym(l, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast) return "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast";
+    g_rccl = r;
+    return nullptr;
+}
+}  // namespace
+
+int rrv_comm_unique_id(char id[128]) {
+    if (!id) return RRV_E_ARG;
+    if (rccl_load()) return RRV_E_COMM;
+    return g_rccl.GetUniqueId(id) == 0 ? RRV_OK : RRV_E_COMM;
+}
+
+int rrv_comm_init_rank(rrv_handle h, const char id[128], int nranks, int rank, void** comm) {
+    if (!h || !id || !comm || nranks < 1 || rank < 0 || rank >= nranks) return RRV_E_ARG;
+    if (const char* e = rccl_load()) return fail(h, RRV_E_COMM, e);
+    HIPCHK(hipSetDevice(h->dev));
+    Rccl::UId u;
+    memcpy(u.b, id, 128);
+    *comm = nullptr;
+    const int rc = g_rccl.CommInitRank(comm, nranks, u, rank);
+    if (rc != 0) return fail(h, RRV_E_COMM, std::string("ncclCommInitRank failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+    return RRV_OK;
+}
+
+int rrv_comm_destroy(void* comm) {
+    if (!comm) return RRV_E_ARG;
+    if (rccl_load()) return RRV_E_COMM;
+    return g_rccl.CommDestroy(comm) == 0 ? RRV_OK : RRV_E_COMM;
+}
+
+// ncclBroadcast of the style's state blob from `root` over `comm` on the handle's stream; every other rank then owns
+// the state exactly as after rrv_set_state (filters folded locally).  One 70 KB message per style and video.
+int rrv_broadcast_state(rrv_handle h, void* comm, int root, int my_rank, int sid) {
+    if (!h || !comm || sid < 0 || sid >= RRV_MAX_STYLES || root < 0 || my_rank < 0) return RRV_E_ARG;
+    if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
+    if (const char* e = rccl_load()) return fail(h, RRV_E_COMM, e);
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    StyleState& S = h->styles[sid];
+    if (my_rank == root && (!S.blob || !S.computed)) return fail(h, RRV_E_STATE, "broadcast_state: the root has no computed state for this style");
+    if (!S.blob) RCHK(dalloc(h, &S.blob, RRV_STATE_FLOATS));
+    const int rc = g_rccl.Broadcast(S.blob, S.blob, RRV_STATE_FLOATS, /* ncclFloat32 */ 7, root, comm, h->streams[0]);
+    if (rc != 0) return fail(h, RRV_E_COMM, std::string("ncclBroadcast failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+    HIPCHK(hipStreamSynchronize(h->streams[0]));
+    if (my_rank != root) {
+        S.computed = true;
+        if (h->active_src == sid || h->active_src < 0) { h->active_src = -1; RCHK(activate_state(h, sid)); }
+    }
     return RRV_OK;
 }
 
@@ -1574,7 +1751,7 @@ int rrv_transfer_blend_device(rrv_handle h, const void* d_in, int H, int W, cons
     }
     hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
     HIPCHK(hipGetLastError());
-    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f, false));
+    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f));
     h->active_src = -2;
     const int rc = transfer_device(h, (const uint8_t*)d_in, 1, H, W, (float*)d_out);
     h->next_slot = 0;
@@ -1584,22 +1761,19 @@ int rrv_transfer_blend_device(rrv_handle h, const void* d_in, int H, int W, cons
 // host-buffer wrappers: H2D, same device path, D2H
 static int host_roundtrip(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out, const float* wts, int ns) {
     if (!h || !frames || !out || B < 1) return RRV_E_ARG;
+    if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "transfer: frames must be at least 8 x 8 pixels");
     HIPCHK(hipSetDevice(h->dev));
-    const size_t n = (size_t)B * H * W * 3;
+    const size_t n = (size_t)B * H * W * 3;                                  // input bytes
+    const size_t no = (size_t)B * (H / 8 * 8) * (W / 8 * 8) * 3;             // output floats: the stylized frame is 8*(H/8) x 8*(W/8)
     RCHK(ensure_u8(h, n));
-    if (h->d_outf_cap < n) {
-        if (h->d_outf) (void)hipFree(h->d_outf);
-        h->d_outf = nullptr; h->d_outf_cap = 0;
-        HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
-        h->d_outf_cap = n;
-    }
+    RCHK(ensure_outf(h, no));
     RCHK(sync_all(h));
     h->next_slot = 0;                                   // the shared staging buffers serialise this path
     HIPCHK(hipMemcpyAsync(h->d_u8, frames, n, hipMemcpyHostToDevice, h->streams[0]));
     if (wts) RCHK(rrv_transfer_blend_device(h, h->d_u8, H, W, wts, ns, h->d_outf));
     else RCHK(rrv_transfer_batch_device(h, h->d_u8, B, H, W, h->d_outf));
     h->next_slot = 0;
-    HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
+    HIPCHK(hipMemcpyAsync(out, h->d_outf, no * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
     HIPCHK(hipStreamSynchronize(h->streams[0]));
     return RRV_OK;
 }
@@ -1642,6 +1816,7 @@ static bool is_pinned(const void* ptr, size_t bytes) {
     }
     return true;
 }
+static int retire_ticket(rrv_handle h, int set);
 static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int W, float* out, bool pad_on_device = false) {
     if (!h || !frames || !out || B < 1) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
@@ -1654,6 +1829,7 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
         if ((ph + 2) * (pw + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
     }
     const bool in_pin = is_pinned(frames, (size_t)B * fb), out_pin = is_pinned(out, (size_t)B * fo * sizeof(float));
+    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));     // open look-ahead tickets own the staging sets
     RCHK(sync_all(h));
     const int nchunk = (B + sub - 1) / sub;
     const int nsets = nchunk < HOST_SETS ? nchunk : HOST_SETS;
@@ -1663,8 +1839,8 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
             if (st.d_in) (void)hipFree(st.d_in);
             if (st.d_out) (void)hipFree(st.d_out);
             st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
-            HIPCHK(hipMalloc((void**)&st.d_in, (size_t)sub * fb));
-            HIPCHK(hipMalloc((void**)&st.d_out, (size_t)sub * fb * sizeof(float)));
+            RCHK(dmalloc(h, (void**)&st.d_in, (size_t)sub * fb));
+            RCHK(dmalloc(h, (void**)&st.d_out, (size_t)sub * fb * sizeof(float)));
             st.cap = (size_t)sub * fb;
         }
         if ((!in_pin || !out_pin) && st.pcap < (size_t)sub * fb) {     // pinned staging only for pageable caller arrays
@@ -1741,6 +1917,82 @@ int rrv_transfer_frames(rrv_handle h, const uint8_t* frames, int B, int H, int W
     return host_pipeline(h, frames, B, H, W, out, true);
 }
 
+// ---- look-ahead form of Stylization.transfer for a one-frame-per-call driver loop (generate_real_video.py:152-171) ----
+// rrv_transfer_async queues H2D copy -> kernels -> D2H copy of ONE frame on the copy / compute streams and returns a
+// ticket at once; rrv_transfer_wait blocks until that frame's output is in `out`.  With the next frame submitted before
+// the previous one is awaited, frame i+1's copy-in and kernels overlap frame i's kernel tails and copy-out (two
+// compute streams, four staging sets: up to four tickets may be open; a fifth submission retires the oldest first).
+// A pageable `frame` is copied into pinned staging before the call returns (the caller may reuse it at once); a
+// pageable `out` is filled by rrv_transfer_wait.  Same arithmetic as rrv_transfer: the results are bit-identical.
+static int retire_ticket(rrv_handle h, int set) {
+    auto& tk = h->tickets[set];
+    if (!tk.open) return RRV_OK;
+    HIPCHK(hipEventSynchronize(h->hstage[set].out_done));
+    if (tk.out) host_copy(tk.out, h->hstage[set].pin_out, tk.out_bytes);
+    tk.open = false;
+    return RRV_OK;
+}
+
+int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* out, long* ticket) {
+    if (!h || !frame || !out || !ticket) return RRV_E_ARG;
+    if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "transfer: frames must be at least 8 x 8 pixels");
+    if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t fb = (size_t)H * W * 3, fo = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
+    const long id = h->next_ticket;
+    const int set = (int)(id % HOST_SETS);
+    auto& st = h->hstage[set];
+    RCHK(retire_ticket(h, set));                                   // the set's previous ticket (four submissions ago)
+    const bool in_pin = is_pinned(frame, fb), out_pin = is_pinned(out, fo * sizeof(float));
+    if (st.cap < fb || st.pcap < fb) {       // (re)size this set: nothing of it is in flight any more
+        if (st.d_in) (void)hipFree(st.d_in);
+        if (st.d_out) (void)hipFree(st.d_out);
+        if (st.pin_in) (void)hipHostFree(st.pin_in);
+        if (st.pin_out) (void)hipHostFree(st.pin_out);
+        st.d_in = nullptr; st.d_out = nullptr; st.pin_in = nullptr; st.pin_out = nullptr; st.cap = 0; st.pcap = 0;
+        RCHK(dmalloc(h, (void**)&st.d_in, fb));
+        RCHK(dmalloc(h, (void**)&st.d_out, fb * sizeof(float)));
+        st.cap = fb;
+        if (hipHostMalloc((void**)&st.pin_in, fb, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&st.pin_out, fb * sizeof(float), hipHostMallocDefault) != hipSuccess)
+            return fail(h, RRV_E_NOMEM, "transfer_async: out of page-locked host memory");
+        st.pcap = fb;
+    }
+    const uint8_t* src = frame;
+    if (!in_pin) { memcpy(st.pin_in, frame, fb); src = st.pin_in; }
+    const int slot = h->profiling ? 0 : (int)(id & 1) % h->n_slots;
+    hipStream_t cs = h->streams[slot];
+    // d_in / d_out of this set were last used by ticket id-4, retired above (its out_done event has fired)
+    HIPCHK(hipMemcpyAsync(st.d_in, src, fb, hipMemcpyHostToDevice, h->copy_in));
+    HIPCHK(hipEventRecord(st.in_done, h->copy_in));
+    HIPCHK(hipStreamWaitEvent(cs, st.in_done, 0));
+    RCHK(ensure_active(h));
+    h->next_slot = slot;
+    const int rc = transfer_device(h, st.d_in, 1, H, W, st.d_out);
+    h->next_slot = 0;
+    if (rc != RRV_OK) return rc;
+    HIPCHK(hipEventRecord(st.k_done, cs));
+    HIPCHK(hipStreamWaitEvent(h->copy_out, st.k_done, 0));
+    HIPCHK(hipMemcpyAsync(out_pin ? (void*)out : (void*)st.pin_out, st.d_out, fo * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
+    HIPCHK(hipEventRecord(st.out_done, h->copy_out));
+    auto& tk = h->tickets[set];
+    tk.id = id; tk.out = out_pin ? nullptr : out; tk.out_bytes = fo * sizeof(float); tk.open = true;
+    h->next_ticket = id + 1;
+    *ticket = id;
+    return RRV_OK;
+}
+
+int rrv_transfer_wait(rrv_handle h, long ticket) {
+    if (!h || ticket < 0 || ticket >= h->next_ticket) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    const int set = (int)(ticket % HOST_SETS);
+    if (h->tickets[set].id != ticket) {
+        if (h->tickets[set].id > ticket) return RRV_OK;            // retired by a later submission: its output is already delivered
+        return fail(h, RRV_E_ARG, "transfer_wait: unknown ticket");
+    }
+    return retire_ticket(h, set);
+}
+
 int rrv_transfer_blend(rrv_handle h, const uint8_t* frame, int H, int W, const float* wts, int ns, float* out) {
     if (!wts) return RRV_E_ARG;
     return host_roundtrip(h, frame, 1, H, W, out, wts, ns);
@@ -1748,29 +2000,57 @@ int rrv_transfer_blend(rrv_handle h, const uint8_t* frame, int H, int W, const f
 
 // ---- multi-style feature API ("Multi-style Interpolation/stylization.py":66-100): the reference caches the
 // encoder output of every frame on disk (test.py:87-101) and feeds it back; here the cache lives in HBM.
+static size_t feature_floats(int H, int W) {      // ring-layout [1, H/8, W/8, 512] image + the same slack as talloc (tile-overrun reads stay inside)
+    const int fh = H / 8, fw = W / 8;
+    return (size_t)(fh + 2) * (fw + 2) * 512 + (size_t)20 * (fw + 2 + 20) * 512;
+}
+
 int rrv_generate_content_features(rrv_handle h, const uint8_t* frame, int H, int W, int* feature_id) {
     if (!h || !frame || !feature_id) return RRV_E_ARG;
     if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
     if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "generate_content_features: frame too small");
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
+    rrv_ctx::Feature ft{nullptr, H, W, nullptr};
+    const size_t need = feature_floats(H, W) * sizeof(float);
+    if (h->feat_bytes + need > h->feat_cap) {        // over the cap: keep the pixels, encode on use
+        RCHK(dmalloc(h, (void**)&ft.u8, (size_t)H * W * 3));
+        HIPCHK(hipMemcpy(ft.u8, frame, (size_t)H * W * 3, hipMemcpyHostToDevice));
+        h->features.push_back(ft);
+        *feature_id = (int)h->features.size() - 1;
+        return RRV_OK;
+    }
     RCHK(ensure_u8(h, (size_t)H * W * 3));
     HIPCHK(hipMemcpyAsync(h->d_u8, frame, (size_t)H * W * 3, hipMemcpyHostToDevice, h->stream));
     RCHK(enc_plan(h, h->enc_add, 1, H, W));
     RCHK(run_encoder(h, h->enc_add, h->d_u8, 0, nullptr, nullptr, 1));
     const Tens& f = h->enc_add.c41;
-    rrv_ctx::Feature ft{nullptr, H, W};
-    const size_t slack = (size_t)20 * (f.W + 2 + 20) * 512;      // same slack as talloc: tile-overrun reads stay inside
-    RCHK(dalloc(h, &ft.p, f.img_floats() + slack, true));
+    RCHK(dalloc(h, &ft.p, feature_floats(H, W), true));
     HIPCHK(hipMemcpyAsync(ft.p, f.p, f.img_floats() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->feat_bytes += need;
     h->features.push_back(ft);
     *feature_id = (int)h->features.size() - 1;
     return RRV_OK;
 }
 
+int rrv_set_feature_cache_cap(rrv_handle h, size_t bytes) {
+    if (!h) return RRV_E_ARG;
+    h->feat_cap = bytes;
+    return RRV_OK;
+}
+int rrv_feature_cache_info(rrv_handle h, int* resident, int* spilled, size_t* bytes) {
+    if (!h) return RRV_E_ARG;
+    int r = 0, sp = 0;
+    for (auto& f : h->features) { r += f.p ? 1 : 0; sp += f.u8 ? 1 : 0; }
+    if (resident) *resident = r;
+    if (spilled) *spilled = sp;
+    if (bytes) *bytes = h->feat_bytes;
+    return RRV_OK;
+}
+
 int rrv_add_patch(rrv_handle h, int feature_id) {
-    if (!h || feature_id < 0 || feature_id >= (int)h->features.size() || !h->features[feature_id].p) return RRV_E_ARG;
+    if (!h || feature_id < 0 || feature_id >= (int)h->features.size() || !(h->features[feature_id].p || h->features[feature_id].u8)) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
     RCHK(flush_pending(h));      // keeps the order of add() and add_patch() calls
@@ -1780,7 +2060,15 @@ int rrv_add_patch(rrv_handle h, int feature_id) {
     Tens f; f.B = 1; f.H = ft.H / 2 / 2 / 2; f.W = ft.W / 2 / 2 / 2; f.C = 512;
     float* keep = nullptr;
     RCHK(dalloc(h, &keep, f.img_floats(), false));
-    HIPCHK(hipMemcpy(keep, ft.p, f.img_floats() * sizeof(float), hipMemcpyDeviceToDevice));
+    const float* src = ft.p;
+    if (!src) {                  // spilled feature: encode its pixels now
+        int rc = enc_plan(h, h->enc_add, 1, ft.H, ft.W);
+        if (rc == RRV_OK) rc = run_encoder(h, h->enc_add, ft.u8, 0, nullptr, nullptr, 1);
+        if (rc == RRV_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, RRV_E_HIP, "add_patch: encoder failed");
+        if (rc != RRV_OK) { (void)hipFree(keep); return rc; }
+        src = h->enc_add.c41.p;
+    }
+    HIPCHK(hipMemcpy(keep, src, f.img_floats() * sizeof(float), hipMemcpyDeviceToDevice));
     h->patches.push_back(keep);
     h->patch_h = f.H; h->patch_w = f.W; h->add_H = ft.H; h->add_W = ft.W;
     return RRV_OK;
@@ -1788,7 +2076,7 @@ int rrv_add_patch(rrv_handle h, int feature_id) {
 
 int rrv_transfer_features(rrv_handle h, int feature_id, const float* wts, int ns, float* out) {
     if (!h || !wts || !out || ns < 1 || ns > RRV_MAX_STYLES) return RRV_E_ARG;
-    if (feature_id < 0 || feature_id >= (int)h->features.size() || !h->features[feature_id].p) return RRV_E_ARG;
+    if (feature_id < 0 || feature_id >= (int)h->features.size() || !(h->features[feature_id].p || h->features[feature_id].u8)) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
     const rrv_ctx::Feature& ft = h->features[feature_id];
@@ -1800,17 +2088,12 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* wts, int ns
     }
     hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
     HIPCHK(hipGetLastError());
-    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f, false));
+    for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f));
     h->active_src = -2;
     const size_t n = (size_t)(ft.H / 8 * 8) * (ft.W / 8 * 8) * 3;
-    if (h->d_outf_cap < n) {
-        if (h->d_outf) (void)hipFree(h->d_outf);
-        h->d_outf = nullptr; h->d_outf_cap = 0;
-        HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
-        h->d_outf_cap = n;
-    }
+    RCHK(ensure_outf(h, n));
     h->next_slot = 0;
-    RCHK(transfer_device(h, nullptr, 1, ft.H, ft.W, h->d_outf, ft.p));
+    RCHK(transfer_device(h, ft.u8, 1, ft.H, ft.W, h->d_outf, ft.p));      // a spilled feature (p == nullptr) is re-encoded from its pixels
     h->next_slot = 0;
     HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
     HIPCHK(hipStreamSynchronize(h->streams[0]));
@@ -1823,12 +2106,13 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
     if (!h || !ids || !wts || !out || n < 1 || ns < 1 || ns > RRV_MAX_STYLES) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     for (int i = 0; i < n; ++i)
-        if (ids[i] < 0 || ids[i] >= (int)h->features.size() || !h->features[ids[i]].p) return fail(h, RRV_E_ARG, "transfer: unknown feature id");
+        if (ids[i] < 0 || ids[i] >= (int)h->features.size() || !(h->features[ids[i]].p || h->features[ids[i]].u8)) return fail(h, RRV_E_ARG, "transfer: unknown feature id");
     for (int s = 0; s < ns; ++s)
         if (!h->styles[s].computed) return fail(h, RRV_E_STATE, "blend: state not computed for every style");
     const int H = h->features[ids[0]].H, W = h->features[ids[0]].W;
     for (int i = 1; i < n; ++i)
         if (h->features[ids[i]].H != H || h->features[ids[i]].W != W) return fail(h, RRV_E_ARG, "transfer: features of one call must share their size");
+    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));
     RCHK(sync_all(h));
     const size_t npx = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
     const bool out_pin = is_pinned(out, (size_t)n * npx * sizeof(float));
@@ -1839,8 +2123,8 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
             if (st.d_in) (void)hipFree(st.d_in);
             if (st.d_out) (void)hipFree(st.d_out);
             st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
-            HIPCHK(hipMalloc((void**)&st.d_in, npx));
-            HIPCHK(hipMalloc((void**)&st.d_out, npx * sizeof(float)));
+            RCHK(dmalloc(h, (void**)&st.d_in, npx));
+            RCHK(dmalloc(h, (void**)&st.d_out, npx * sizeof(float)));
             st.cap = npx;
         }
         if (!out_pin && st.pcap < npx) {
@@ -1873,10 +2157,10 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
         for (int s = 0; s < ns; ++s) { bp.st[s] = h->styles[s].blob; bp.w[s] = wts[(size_t)i * ns + s]; }
         hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
         HIPCHK(hipGetLastError());
-        for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f, false));
+        for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f));
         h->active_src = -2;
         h->next_slot = slot;
-        RCHK(transfer_device(h, nullptr, 1, H, W, st.d_out, h->features[ids[i]].p));
+        RCHK(transfer_device(h, h->features[ids[i]].u8, 1, H, W, st.d_out, h->features[ids[i]].p));
         HIPCHK(hipEventRecord(st.k_done, h->streams[slot]));
         HIPCHK(hipStreamWaitEvent(h->copy_out, st.k_done, 0));
         HIPCHK(hipMemcpyAsync(out_pin ? (void*)(out + (size_t)i * npx) : (void*)st.pin_out, st.d_out, npx * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
@@ -1891,8 +2175,9 @@ int rrv_release_features(rrv_handle h) {
     if (!h) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
-    for (auto& f : h->features) if (f.p) (void)hipFree(f.p);
+    for (auto& f : h->features) { if (f.p) (void)hipFree(f.p); if (f.u8) (void)hipFree(f.u8); }
     h->features.clear();
+    h->feat_bytes = 0;
     return RRV_OK;
 }
 
@@ -1911,12 +2196,7 @@ int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame, int H, int W, fl
     const size_t n = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;       // the stylized frame is 8*(H/8) x 8*(W/8)
     RCHK(ensure_u8(h, nin));
     HIPCHK(hipMemcpyAsync(h->d_u8, frame, nin, hipMemcpyHostToDevice, h->stream));
-    if (h->d_outf_cap < n) {
-        if (h->d_outf) (void)hipFree(h->d_outf);
-        h->d_outf = nullptr; h->d_outf_cap = 0;
-        HIPCHK(hipMalloc((void**)&h->d_outf, n * sizeof(float)));
-        h->d_outf_cap = n;
-    }
+    RCHK(ensure_outf(h, n));
     RCHK(frame_mode_forward(h, h->d_u8, H, W, h->d_outf));
     HIPCHK(hipMemcpyAsync(out, h->d_outf, n * sizeof(float), hipMemcpyDeviceToHost, h->streams[0]));
     HIPCHK(hipStreamSynchronize(h->streams[0]));

@@ -76,7 +76,9 @@ class Stylization():
     def _chk(self, rc):
         if rc != 0:
             msg = self._lib.rrv_last_error(self._h)
-            raise RRVError("librerevst_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+            err = RRVError("librerevst_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+            err.code = rc          # RRV_E_* of include/rerevst_hip.h (-5 = RRV_E_NOMEM)
+            raise err
 
     def close(self):
         if getattr(self, "_h", None):
@@ -109,6 +111,10 @@ class Stylization():
 
     def debug_selftest(self):
         self._chk(self._lib.rrv_debug_selftest(self._h))
+
+    def debug_fail_alloc(self, nth):
+        """Failure injection: the nth next device allocation reports out-of-memory (0 disarms)."""
+        self._chk(self._lib.rrv_debug_fail_alloc(self._h, int(nth)))
 
     def set_workspace_cap(self, nbytes):
         """compute() keeps all sampled frames' activations resident while they fit `nbytes` (default 64 GiB); beyond
@@ -150,6 +156,38 @@ class Stylization():
         w = (C.c_float * len(style_weight))(*[float(v) for v in style_weight])
         self._chk(self._lib.rrv_transfer_blend(self._h, a.ctypes.data_as(C.c_void_p), H, W, w, len(style_weight),
                                                out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ===== look-ahead form of transfer() for a one-frame-per-call loop =====
+    def transfer_async(self, frame, out=None):
+        """Queue one frame (H2D copy, kernels, D2H copy) and return a ticket at once; ``result(ticket)`` returns the
+        stylized frame.  A driver loop written as
+
+            prev = None
+            for frame in frames:
+                t = framework.transfer_async(frame)
+                if prev is not None: write(framework.result(prev))
+                prev = t
+            write(framework.result(prev))
+
+        overlaps frame i+1's copy-in and kernels with frame i's kernel tails, copy-out and file write.  Up to four
+        tickets may be open.  Same arithmetic as transfer(): bit-identical results."""
+        if not self.use_Global:
+            raise RRVError("transfer_async() needs the global-feature-sharing model (use_Global=True)")
+        a = _u8_image(frame, "frame")
+        H, W = a.shape[:2]
+        oshape = (H // 8 * 8, W // 8 * 8, 3)
+        if out is None:
+            out = np.empty(oshape, dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != oshape or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape %r" % (oshape,))
+        t = C.c_long(-1)
+        self._chk(self._lib.rrv_transfer_async(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p), C.byref(t)))
+        return (t.value, out)
+
+    def result(self, ticket):
+        tid, out = ticket
+        self._chk(self._lib.rrv_transfer_wait(self._h, tid))
         return out
 
     # ===== device-resident entry (what bench.py times) =====
@@ -221,6 +259,26 @@ class Stylization():
         if b.size != _lib.STATE_FLOATS:
             raise ValueError("state blob must have %d floats" % _lib.STATE_FLOATS)
         self._chk(self._lib.rrv_set_state(self._h, b.ctypes.data_as(C.c_void_p), b.size, style_id))
+
+    # ===== the path's one collective through the C ABI (RCCL; rerevst_hip.h: rrv_comm_*, rrv_broadcast_state) =====
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        if self._lib.rrv_comm_unique_id(buf) != 0:
+            raise RRVError("rrv_comm_unique_id failed (librccl.so not found? set RRV_RCCL_PATH)")
+        return bytes(buf.raw)
+
+    def comm_init_rank(self, unique_id, nranks, rank):
+        comm = C.c_void_p()
+        self._chk(self._lib.rrv_comm_init_rank(self._h, C.create_string_buffer(bytes(unique_id), 128), int(nranks), int(rank), C.byref(comm)))
+        return comm
+
+    def comm_destroy(self, comm):
+        if self._lib.rrv_comm_destroy(comm) != 0:
+            raise RRVError("rrv_comm_destroy failed")
+
+    def broadcast_state(self, comm, root, rank, style_id=0):
+        """ncclBroadcast of the style's 17 536-float state from `root`; afterwards this rank holds it as after set_state."""
+        self._chk(self._lib.rrv_broadcast_state(self._h, comm, int(root), int(rank), int(style_id)))
 
     def preclamp(self, H, W):
         """Pre-clamp network output of the last transfer, NHWC RGB normalised units."""
@@ -297,3 +355,14 @@ class MultiStyleStylization(Stylization):
 
     def release_features(self):
         self._chk(self._lib.rrv_release_features(self._h))
+
+    def set_feature_cache_cap(self, nbytes):
+        """Features are cached in HBM up to `nbytes` (default 64 GiB); beyond that a frame is kept as uint8 pixels and
+        re-encoded at every use (the reference's cache is on disk: "Multi-style Interpolation/test.py":87-101)."""
+        self._chk(self._lib.rrv_set_feature_cache_cap(self._h, int(nbytes)))
+
+    def feature_cache_info(self):
+        """(cached features, spilled features, bytes held by the cached ones)."""
+        r, sp, b = C.c_int(), C.c_int(), C.c_size_t()
+        self._chk(self._lib.rrv_feature_cache_info(self._h, C.byref(r), C.byref(sp), C.byref(b)))
+        return r.value, sp.value, b.value

@@ -84,6 +84,38 @@ def synthetic_weights(seed=0):
     return out
 
 
+def weight_variant(name):
+    """Named weight sets of the parity fixtures (tests/golden/make_goldens.py; all derived from the seeded generator,
+    so only the name travels).  One draw is one draw: the variants change the dynamic range the kernels see.
+
+    seed0 / seed1  two independent draws
+    dec2 / dec4    seed 0 with every Decoder.* weight tensor (convs and FilterPredictor FCs, not the biases) x 2 / x 4:
+                   larger dynamic filters (entries up to 24 at x 4), residuals and pre-clamp outputs.  At x 4 the saved
+                   state is ill-conditioned in fp32 — the reference's own 1-thread and 8-thread runs differ by 30x the
+                   state bound — so that fixture also carries the reference's float64 state (see tests/conftest.py)
+    dead           seed 0 with dead / constant channels: 16 relu4_1 channels and 8 relu2_1 channels of both encoders
+                   exactly zero (zero weights, bias -1 before the ReLU: variance 0, rstd = 1e4, style std = sqrt(1e-5)),
+                   and 4 constant channels (zero weights, bias 0.3) out of Decoder.slice3.conv1 — the saved-statistics
+                   normalisation of a channel without any spread
+    """
+    if name in ("seed0", "seed1"):
+        return synthetic_weights(int(name[-1]))
+    w = synthetic_weights(0)
+    if name in ("dec2", "dec4"):
+        for k in w:
+            if k.startswith("Decoder.") and k.endswith(".weight"):
+                w[k] = (w[k] * np.float32(name[-1])).astype(np.float32)
+        return w
+    if name == "dead":
+        for pre, n in (("Encoder.slice.19.", 16), ("EncoderStyle.slice4.19.", 16), ("Encoder.slice.5.", 8), ("EncoderStyle.slice2.5.", 8)):
+            w[pre + "weight"][:n] = 0.0
+            w[pre + "bias"][:n] = -1.0
+        w["Decoder.slice3.conv1.weight"][:4] = 0.0
+        w["Decoder.slice3.conv1.bias"][:4] = 0.3
+        return w
+    raise ValueError("unknown weight variant %r" % (name,))
+
+
 def load_checkpoint(path):
     """Read a reference ``.pth`` (torch.save'd state_dict) into the same {key: ndarray} form."""
     import torch  # plumbing only: unpickles the tensors

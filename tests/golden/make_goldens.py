@@ -52,7 +52,7 @@ def nhwc(t):
     return t.detach().cpu().numpy().transpose(0, 2, 3, 1).copy()
 
 
-def ref_state_blob(model):
+def _blob_parts(model):
     d = model.Decoder
     norms = list(d.norm) + [d.slice4.norm1, d.slice4.norm2, d.slice3.norm1, d.slice3.norm2,
                             d.slice2.norm1, d.slice2.norm2]
@@ -66,12 +66,40 @@ def ref_state_blob(model):
     for name in O.STYLE_NAMES:
         ms = getattr(model.F_style, name)
         parts += [ms.mean.reshape(-1).numpy(), ms.std.reshape(-1).numpy()]
-    blob = np.concatenate(parts).astype(np.float32)
+    return parts
+
+
+def ref_state_blob(model):
+    blob = np.concatenate(_blob_parts(model)).astype(np.float32)
     assert blob.size == O.STATE_FLOATS
     return blob
 
 
-def run_case(name, weights, style_hw, frame_hw, n_frames, sample_ids, transfer_id, crop_only):
+def ref_fp64(weights, style, frames, sample_ids, padded):
+    """The reference network run in float64 (model.double(), inputs cast): the exact answer its float32 arithmetic
+    approximates.  Returns (state blob, pre-clamp output) as float64."""
+    s, G = load_ref(weights)
+    s.model.double()
+    fw = sys.modules["framework"]
+    orig = fw.numpy2tensor
+    fw.numpy2tensor = lambda img: orig(img).double()
+    try:
+        s.prepare_style(style)
+        s.clean()
+        for i in sample_ids:
+            s.add(frames[i])
+        s.compute()
+        blob = np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in _blob_parts(s.model)])
+        taps = {}
+        hk = s.model.Decoder.slice1.register_forward_hook(lambda m, i, o: taps.__setitem__("pre", nhwc(o)))
+        s.transfer(padded.copy())
+        hk.remove()
+    finally:
+        fw.numpy2tensor = orig
+    return blob, taps["pre"][0]
+
+
+def run_case(name, weights, style_hw, frame_hw, n_frames, sample_ids, transfer_id, crop_only, fp64=False):
     s, G = load_ref(weights)
     style = pkg.synth_style(*style_hw, kind="smooth", seed=7)
     frames = [pkg.synth_frame(i, *frame_hw, kind="smooth") for i in range(n_frames)]
@@ -119,6 +147,14 @@ def run_case(name, weights, style_hw, frame_hw, n_frames, sample_ids, transfer_i
             continue
         g["tap_%s_chanmean" % k] = v.mean(axis=(0, 1, 2)).astype(np.float32)
         g["tap_%s_corner" % k] = v[0, :6, :6, :].astype(np.float32)
+    if fp64:      # ill-conditioned weight sets: the exact (float64) reference next to its float32 run
+        b64, p64 = ref_fp64(weights, style, frames, sample_ids, padded)
+        g["state_fp64"] = b64
+        g["pre_fp64"] = p64.astype(np.float32)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import conftest as C
+        print("[%s] reference float32 vs its own float64: state worst %.1fx bound (%s); pre-clamp max|d| %.3e | oracle vs float64: %.1fx"
+              % (name, *C.state_worst(blob, b64), np.abs(pre - p64).max(), C.state_worst(oblob, b64)[0]))
     if crop_only:
         g["pre_crop"] = pre[64:64 + H, 64:64 + W].astype(np.float32)
         g["out_crop"] = out[64:64 + H, 64:64 + W].astype(np.float32)
@@ -245,7 +281,114 @@ def run_config2(name, weights):
              pre_chanmean=pre.mean(axis=(0, 1)).astype(np.float32), out_chanmean=out.mean(axis=(0, 1)).astype(np.float32))
 
 
+# ---- the reference's OWN inputs (round 3): test/inputs/plum_flower.jpg + test/inputs/ambush_4 (the defaults of
+# test/generate_real_video.py:19,24) and data/img_1.jpg (BASELINE config 1).  The decoded uint8 pixels are stored in
+# the fixture (as lossless PNG streams), so codec differences between cv2 and Pillow are moot.
+def _imread_bgr(path):
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[..., ::-1])
+
+
+def _png(img_bgr):
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(img_bgr[..., ::-1])).save(b, format="PNG", optimize=True)
+    return np.frombuffer(b.getvalue(), dtype=np.uint8)
+
+
+def _drive(s, style, frames, transfer_ids):
+    """generate_real_video.py:95-171 on decoded frames: prepare_style, clean, add every 8th + last frame UNPADDED,
+    compute, then ReshapeTool.process -> transfer -> crop for the requested frames.  Returns state, {id: (pre, out)} crops."""
+    s.prepare_style(style)
+    s.clean()
+    ids = O.sample_indices(len(frames))
+    for i in ids:
+        s.add(frames[i])
+    s.compute()
+    blob = ref_state_blob(s.model)
+    H, W = frames[0].shape[:2]
+    PH, PW = O.padded_size(H), O.padded_size(W)
+    res = {}
+    for tid in transfer_ids:
+        padded = O.reflect_pad(frames[tid], PH, PW)
+        taps = {}
+        hk = s.model.Decoder.slice1.register_forward_hook(lambda m, i, o: taps.__setitem__("pre", nhwc(o)))
+        out = s.transfer(padded.copy())
+        hk.remove()
+        res[tid] = (taps["pre"][0][64:64 + H, 64:64 + W], out[64:64 + H, 64:64 + W])
+    return blob, ids, res
+
+
+def run_real_default(name, weights):
+    """The reference's default invocation: plum_flower.jpg at its native 400x564 (564 is not a multiple of 8) on the 33
+    ambush_4 Sintel frames, 436x1024 (436 is not a multiple of 8), sampled 0,8,16,24 + last, one non-sampled frame
+    (index 12) padded to 576x1152.  Stored: decoded inputs (PNG), state, stride-4 grid + channel means + one dense
+    64x64 patch of the pre-clamp / final crop."""
+    import glob
+    s, G = load_ref(weights)
+    style = _imread_bgr(R.REF_ROOT + "/test/inputs/plum_flower.jpg")
+    paths = sorted(glob.glob(R.REF_ROOT + "/test/inputs/ambush_4/*.png"))
+    frames = [_imread_bgr(p) for p in paths]
+    assert style.shape == (400, 564, 3) and len(frames) == 33 and frames[0].shape == (436, 1024, 3)
+    tid = 12
+    blob, ids, res = _drive(s, style, frames, [tid])
+    pre, out = res[tid]
+    O.set_conv_backend("torch")
+    o = O.Stylization(weights)
+    o.prepare_style(style); o.clean()
+    for i in ids:
+        o.add(frames[i])
+    o.compute()
+    rel = np.abs(o.get_state() - blob) / (np.abs(blob) + 1e-3)
+    padded = O.reflect_pad(frames[tid], 576, 1152)
+    opre = o.transfer(padded, return_preclamp=True)[0][64:500, 64:1088]
+    O.set_conv_backend("numpy")
+    print("[%s] B=%d | oracle state rel err max %.3e | pre-clamp max|d| %.3e (std %.3f) | sat frac %.3f"
+          % (name, len(ids), rel.max(), np.abs(opre - pre).max(), pre.std(), float(np.mean((out <= 0) | (out >= 255)))))
+    g = dict(state=blob, sample_ids=np.array(ids), transfer_id=np.array(tid), style_png=_png(style),
+             pre_grid=pre[::4, ::4].astype(np.float32), out_grid=out[::4, ::4].astype(np.float32),
+             pre_patch=pre[186:250, 480:544].astype(np.float32), out_patch=out[186:250, 480:544].astype(np.float32),
+             pre_chanmean=pre.mean(axis=(0, 1)).astype(np.float32), out_chanmean=out.mean(axis=(0, 1)).astype(np.float32),
+             style_map_chansum=nhwc(s.model.F_style.map).sum(axis=(0, 1, 2)).astype(np.float32))
+    for k, i in enumerate(ids + [tid]):
+        g["frame%d_png" % i] = _png(frames[i])
+    np.savez(os.path.join(HERE, name + ".npz"), **g)
+
+
+def run_img1_256(name, weights):
+    """BASELINE config 1: data/img_1.jpg (512x512) as style on ONE 256x256 frame (a crop of ambush_4/frame_0001.png):
+    N = 1, so the driver adds the frame itself (B = 1) and stylizes it padded to 384x384."""
+    s, G = load_ref(weights)
+    style = _imread_bgr(R.REF_ROOT + "/data/img_1.jpg")
+    frame = np.ascontiguousarray(_imread_bgr(R.REF_ROOT + "/test/inputs/ambush_4/frame_0001.png")[90:346, 384:640])
+    assert style.shape == (512, 512, 3) and frame.shape == (256, 256, 3)
+    blob, ids, res = _drive(s, style, [frame], [0])
+    pre, out = res[0]
+    o = O.Stylization(weights)
+    o.set_state(blob)
+    opre = o.transfer(O.reflect_pad(frame, 384, 384), return_preclamp=True)[0][64:320, 64:320]
+    print("[%s] B=%d | oracle (reference state) pre-clamp max|d| %.3e (std %.3f) | sat frac %.3f"
+          % (name, len(ids), np.abs(opre - pre).max(), pre.std(), float(np.mean((out <= 0) | (out >= 255)))))
+    np.savez(os.path.join(HERE, name + ".npz"), state=blob, style_png=_png(style), frame_png=_png(frame),
+             pre_grid=pre[::2, ::2].astype(np.float32), out_grid=out[::2, ::2].astype(np.float32),
+             pre_chanmean=pre.mean(axis=(0, 1)).astype(np.float32), out_chanmean=out.mean(axis=(0, 1)).astype(np.float32))
+
+
 def main():
+    only = set(sys.argv[1:])
+    if only:       # regenerate selected cases: python make_goldens.py real_default img1_256 global_a_seed1 ...
+        for name in sorted(only):
+            if name == "real_default":
+                run_real_default(name, pkg.synthetic_weights(0))
+            elif name == "img1_256":
+                run_img1_256(name, pkg.synthetic_weights(0))
+            elif name.startswith("global_a_"):
+                run_case(name, pkg.weight_variant(name[len("global_a_"):]), (64, 64), (64, 48), 4, [0, 1, 3], 2, crop_only=False,
+                         fp64=name.endswith("dec4"))
+            else:
+                raise SystemExit("unknown case " + name)
+        return
     w = pkg.synthetic_weights(0)
     # A: 3 sampled frames (Q1,Q3,Q4), transfer of a NON-sampled frame, full padded output
     run_case("global_a", w, (64, 64), (64, 48), 4, [0, 1, 3], 2, crop_only=False)
@@ -255,6 +398,11 @@ def main():
     run_multistyle("multistyle_s4", w, S=4, wts=(0.1, 0.2, 0.3, 0.4))
     run_frame_mode("frame_mode", w)
     run_config2("config2_256", w)
+    # round 3: the reference's own inputs, a second weight draw, wider / degenerate dynamic ranges
+    run_real_default("real_default", w)
+    run_img1_256("img1_256", w)
+    for v in ("seed1", "dec4", "dead"):
+        run_case("global_a_" + v, pkg.weight_variant(v), (64, 64), (64, 48), 4, [0, 1, 3], 2, crop_only=False, fp64=(v == "dec4"))
 
 
 if __name__ == "__main__":

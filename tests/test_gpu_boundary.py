@@ -218,3 +218,175 @@ def test_bounds_checked_debug_mode(pkg, weights, oracle):
     plain, checked = flow(0), flow(2)
     for a, b in zip(plain, checked):
         np.testing.assert_array_equal(a, b)
+
+
+# ---- round 3 -----------------------------------------------------------------------------------------------------
+def test_blend_transfer_of_a_frame_whose_size_is_not_a_multiple_of_8(pkg, weights, oracle):
+    """transfer(frame, style_weight) at 67x93: the stylized frame is 64x88 and the host copy must be sized for THAT
+    (the D2H copy was sized H*W*3 floats — a heap overflow past the caller's array)."""
+    style = pkg.synth_style(40, 56, kind="smooth", seed=11)
+    sampled = [pkg.synth_frame(i, 37, 53, kind="smooth", seed=50) for i in range(2)]
+    s = pkg.Stylization(weights, cuda=True, style_num=2)
+    s.prepare_style([style, style[::-1].copy()])
+    s.clean()
+    for f in sampled:
+        s.add(f)
+    s.compute()
+    frame = pkg.synth_frame(5, 67, 93, kind="smooth", seed=51)
+    guard = np.full((64 * 88 * 3 + 4096,), -7.0, np.float32)        # the result lands in the middle of a canary buffer
+    out = guard[1024:1024 + 64 * 88 * 3].reshape(64, 88, 3)
+    a = np.ascontiguousarray(frame)
+    import ctypes as C
+    w = (C.c_float * 2)(0.25, 0.75)
+    s._chk(s._lib.rrv_transfer_blend(s._h, a.ctypes.data_as(C.c_void_p), 67, 93, w, 2, out.ctypes.data_as(C.c_void_p)))
+    assert (guard[:1024] == -7.0).all() and (guard[1024 + 64 * 88 * 3:] == -7.0).all()
+    got = s.transfer(frame, style_weight=[0.25, 0.75])
+    assert got.shape == (64, 88, 3)
+    np.testing.assert_array_equal(got, out)
+    o = oracle.MultiStylization(weights, 2)
+    o.prepare_style([style, style[::-1].copy()])
+    o.clean()
+    for f in sampled:
+        o.add_patch(o.generate_content_features(f))
+    o.compute_norm()
+    ref = o.transfer(o.generate_content_features(frame), [0.25, 0.75])
+    assert ref.shape == (64, 88, 3) and np.abs(got - ref).max() <= IMG_ATOL
+    with pytest.raises(pkg.RRVError):
+        s.transfer(np.zeros((7, 40, 3), np.uint8), style_weight=[0.5, 0.5])
+    s.close()
+
+
+def test_allocation_failure_leaves_no_half_built_workspace(hip, pkg, oracle):
+    """rrv_debug_fail_alloc: an out-of-memory in the middle of building a workspace is RRV_E_NOMEM, and the next call
+    with the SAME geometry rebuilds it (the plan recorded its geometry before the allocations, so the
+    retry passed the cache test and launched kernels on null tensors)."""
+    frame = oracle.reflect_pad(pkg.synth_frame(900, 40, 56, kind="smooth"), 104, 120)      # a geometry no other test of this handle uses
+    fails = 0
+    for nth in range(1, 64):             # every allocation of the chain fails once: staging, 9 encoder tensors, 14 decoder ones, the split-K partials
+        hip.debug_fail_alloc(nth)
+        try:
+            hip.transfer_batch([frame, frame, frame])
+        except pkg.RRVError as e:
+            assert e.code == -5 and "out of device memory" in str(e), str(e)
+            fails += 1
+            continue
+        finally:
+            hip.debug_fail_alloc(0)
+        break
+    assert fails >= 12, fails
+    ref = hip.transfer(frame)
+    got = hip.transfer_batch([frame, frame, frame])
+    for k in range(3):
+        np.testing.assert_array_equal(got[k], ref)
+
+
+def test_two_frame_sizes_alternate_without_reallocating(hip, pkg, oracle):
+    """Two workspace geometries stay resident per slot: alternating between two frame sizes gives the same bits as
+    running each size alone, and a third size evicts only the least recently used one."""
+    a = oracle.reflect_pad(pkg.synth_frame(910, 40, 56, kind="smooth"), 128, 128)
+    b = oracle.reflect_pad(pkg.synth_frame(911, 90, 50, kind="smooth"), 192, 128)
+    c = oracle.reflect_pad(pkg.synth_frame(912, 24, 24, kind="smooth"), 64, 64)
+    ra, rb, rc = hip.transfer(a), hip.transfer(b), hip.transfer(c)
+    hip.debug_fail_alloc(1)              # from here on ANY device allocation would fail ...
+    try:
+        for _ in range(3):               # ... but c (just used) and b alternate inside the two resident plans
+            np.testing.assert_array_equal(hip.transfer(c), rc)
+            np.testing.assert_array_equal(hip.transfer(b), rb)
+    finally:
+        hip.debug_fail_alloc(0)
+    np.testing.assert_array_equal(hip.transfer(a), ra)
+
+
+def test_async_tickets_equal_plain_transfer(hip, pkg, oracle):
+    """rrv_transfer_async / rrv_transfer_wait (the look-ahead loop of a one-frame-per-call driver): same bits as
+    transfer(), in any await order, with more submissions than staging sets, pageable and page-locked outputs."""
+    frames = [oracle.reflect_pad(pkg.synth_frame(920 + i, 40, 56, kind="noise"), 128, 128) for i in range(11)]
+    ref = [hip.transfer(f) for f in frames]
+    prev, got = None, []
+    for f in frames:                                   # the driver loop: submit i+1, then collect i
+        t = hip.transfer_async(f)
+        if prev is not None:
+            got.append(hip.result(prev))
+        prev = t
+    got.append(hip.result(prev))
+    for k in range(11):
+        np.testing.assert_array_equal(got[k], ref[k])
+    tickets = [hip.transfer_async(f) for f in frames[:4]]          # four open tickets, collected backwards
+    for k in (3, 1, 2, 0):
+        np.testing.assert_array_equal(hip.result(tickets[k]), ref[k])
+    tickets = [hip.transfer_async(f) for f in frames[:7]]          # more than four: the oldest are retired by later submissions
+    for k in range(7):
+        np.testing.assert_array_equal(hip.result(tickets[k]), ref[k])
+    pin = pkg.pinned_empty((2,) + ref[0].shape, np.float32)
+    t0 = hip.transfer_async(frames[0], out=pin[0])
+    t1 = hip.transfer_async(frames[1], out=pin[1])
+    batch = hip.transfer_batch(frames[2:5])                        # another entry in between retires the open tickets first
+    np.testing.assert_array_equal(hip.result(t1), ref[1])
+    np.testing.assert_array_equal(hip.result(t0), ref[0])
+    for k in range(3):
+        np.testing.assert_array_equal(batch[k], ref[2 + k])
+    odd = pkg.synth_frame(940, 67, 93, kind="noise")               # 8*(H/8) x 8*(W/8) output
+    np.testing.assert_array_equal(hip.result(hip.transfer_async(odd)), hip.transfer(odd))
+
+
+def test_feature_cache_cap_falls_back_to_reencoding(pkg, weights, oracle):
+    """rrv_set_feature_cache_cap with a deliberately tiny cap: features beyond it are kept as pixels and re-encoded at
+    every use (the reference spills to disk and is unbounded, test.py:87-101) — same images to rounding, never an error."""
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7 + k) for k in range(2)]
+    frames = [oracle.reflect_pad(pkg.synth_frame(i, 64, 48, kind="smooth"), 192, 192) for i in range(5)]
+    def flow(cap):
+        s = pkg.MultiStyleStylization(weights, cuda=True, style_num=2)
+        if cap is not None:
+            s.set_feature_cache_cap(cap)
+        s.prepare_style(styles)
+        feats = [s.generate_content_features(f) for f in frames]
+        info = s.feature_cache_info()
+        s.clean()
+        for i in (0, 2, 4):
+            s.add_patch(feats[i])
+        s.compute_norm()
+        st = [s.get_state(k) for k in range(2)]
+        one = s.transfer(feats[1], [0.3, 0.7])
+        many = s.transfer_many(feats, [[k / 4.0, 1 - k / 4.0] for k in range(5)])
+        s.release_features()
+        assert s.feature_cache_info() == (0, 0, 0)
+        s.close()
+        return info, st, one, many
+    info_all, st_all, one_all, many_all = flow(None)
+    per = (24 + 2) * (24 + 2) * 512 * 4
+    info_cap, st_cap, one_cap, many_cap = flow(2 * per + 3 * 20 * 46 * 512 * 4)        # room for two features
+    assert info_all[:2] == (5, 0) and info_cap[:2] == (2, 3)
+    for a, b in zip(st_all, st_cap):                                    # spilled features were re-encoded for add_patch: same encoder, same bits
+        np.testing.assert_array_equal(a, b)
+    # a re-encoded frame normalises inside the encoder's epilogue instead of a pointwise pass over the cached feature
+    assert np.abs(one_cap - one_all).max() <= IMG_ATOL and np.abs(many_cap - many_all).max() <= IMG_ATOL
+    np.testing.assert_array_equal(many_cap[:2], many_all[:2])           # the two cached ones are untouched
+
+
+def test_c_abi_rccl_broadcast_single_rank(hip, pkg):
+    """rrv_comm_unique_id -> rrv_comm_init_rank -> rrv_broadcast_state (ncclBroadcast through the dlopen'ed librccl) at
+    world size 1: the north star's RCCL broadcast as a C symbol; the state is unchanged and transfers still work."""
+    before = hip.get_state()
+    comm = hip.comm_init_rank(hip.comm_unique_id(), 1, 0)
+    hip.broadcast_state(comm, 0, 0, 0)
+    hip.comm_destroy(comm)
+    np.testing.assert_array_equal(hip.get_state(), before)
+    with pytest.raises(pkg.RRVError):
+        hip.broadcast_state(None, 0, 0, 0)
+
+
+def test_bench_nccl_process_group_at_world_size_one():
+    """bench.py forced through init_process_group("nccl", device_id=...), barrier, broadcast, all_gather, all_reduce on
+    CUDA tensors at world size 1 (RCCL runs fine with one rank): the branch the 8-GPU run takes, executed here."""
+    env = dict(os.environ, RRV_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29900 + os.getpid() % 90))
+    env.pop("RRV_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--size", "256",
+           "--batch", "8", "--frames", "20", "--no-cpu-baseline", "--no-extras", "--profile-steps", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["value"] > 0
+    pr = j["per_rank"]
+    assert pr["process_group"] == "nccl" and len(pr["frames_per_s"]) == 1 and pr["min"] == pr["max"] > 0
+    assert pr["c_abi_rccl_broadcast"].startswith("ok") and "bit-identical" in pr["c_abi_rccl_broadcast"], pr

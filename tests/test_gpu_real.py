@@ -1,0 +1,90 @@
+"""GPU parity (run with -m gpu) on the reference's OWN inputs and on further weight sets — round 3.
+* real_default: test/generate_real_video.py's default invocation (plum_flower.jpg at its native 400x564 on the
+  ambush_4 frames at 436x1024: neither size is a multiple of 8), frame 12 padded to 576x1152;
+* img1_256: BASELINE config 1 (data/img_1.jpg on one 256x256 natural frame, B = 1);
+* global_a with a second weight draw, with dead / constant channels, and with every decoder weight x 4.
+All through the C ABI against outputs of the unmodified reference (tests/golden/make_goldens.py)."""
+import numpy as np
+import pytest
+
+from conftest import (load_golden, golden_inputs, decode_png, assert_state_close, assert_pre_close,
+                      assert_state_close_conditioned, IMG_ATOL)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_real_default_matches_reference(pkg, weights, oracle):
+    g = load_golden("real_default")
+    style = decode_png(g["style_png"])
+    ids, tid = [int(i) for i in g["sample_ids"]], int(g["transfer_id"])
+    s = pkg.Stylization(weights, cuda=True)
+    s.prepare_style(style)                       # 400 x 564: odd-sized relu1_1..relu4_1 pyramid in chan_stats(mode 2)
+    s.clean()
+    for i in ids:
+        s.add(decode_png(g["frame%d_png" % i]))  # 436 x 1024, unpadded (Q6)
+    s.compute()
+    assert_state_close(s.get_state(), g["state"])
+    frame = decode_png(g["frame%d_png" % tid])
+    out = s.transfer(oracle.reflect_pad(frame, 576, 1152))[64:500, 64:1088]
+    pre = s.preclamp(576, 1152)[64:500, 64:1088]
+    assert_pre_close(pre[::4, ::4], g["pre_grid"])
+    assert_pre_close(pre[186:250, 480:544], g["pre_patch"])
+    np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=2e-5)
+    assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
+    assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
+    np.testing.assert_allclose(out.mean(axis=(0, 1)), g["out_chanmean"], atol=2e-3)
+    # the on-device pad / crop entry (what driver.py uses) delivers the same pixels
+    np.testing.assert_array_equal(s.transfer_frames([frame])[0], out)
+    s.close()
+
+
+def test_img1_256_matches_reference(pkg, weights, oracle):
+    g = load_golden("img1_256")
+    style, frame = decode_png(g["style_png"]), decode_png(g["frame_png"])
+    s = pkg.Stylization(weights, cuda=True)
+    s.prepare_style(style)
+    s.clean()
+    s.add(frame)
+    s.compute()
+    assert_state_close(s.get_state(), g["state"])
+    out = s.transfer(oracle.reflect_pad(frame, 384, 384))[64:320, 64:320]
+    pre = s.preclamp(384, 384)[64:320, 64:320]
+    assert_pre_close(pre[::2, ::2], g["pre_grid"])
+    np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=2e-5)
+    assert np.abs(out[::2, ::2] - g["out_grid"]).max() <= IMG_ATOL
+    np.testing.assert_allclose(out.mean(axis=(0, 1)), g["out_chanmean"], atol=2e-3)
+    s.close()
+
+
+def _flow(pkg, oracle, variant):
+    g = load_golden("global_a_" + variant)
+    style, frames, ids, tid = golden_inputs(pkg, g)
+    s = pkg.Stylization(pkg.weight_variant(variant), cuda=True)
+    s.prepare_style(style)
+    s.clean()
+    for i in ids:
+        s.add(frames[i])
+    s.compute()
+    return g, s, oracle.reflect_pad(frames[tid], 192, 192)
+
+
+@pytest.mark.parametrize("variant", ["seed1", "dead"])
+def test_weight_variants_match_reference(variant, pkg, oracle):
+    g, s, padded = _flow(pkg, oracle, variant)
+    assert_state_close(s.get_state(), g["state"])
+    out = s.transfer(padded)
+    assert_pre_close(s.preclamp(192, 192), g["pre"])
+    assert np.abs(out - g["out"]).max() <= IMG_ATOL
+    s.close()
+
+
+def test_ill_conditioned_weights_dec4(pkg, oracle):
+    """The per-frame path with the reference's state inside the regular bound; the saved state (ill-conditioned in
+    float32: tests/state_bounds.py) relative to the reference's own distance from its float64 run."""
+    g, s, padded = _flow(pkg, oracle, "dec4")
+    assert_state_close_conditioned(s.get_state(), g["state"], g["state_fp64"])
+    s.set_state(g["state"])
+    out = s.transfer(padded)
+    assert_pre_close(s.preclamp(192, 192), g["pre"])
+    assert np.abs(out - g["out"]).max() <= IMG_ATOL
+    s.close()

@@ -4,7 +4,7 @@ import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import conftest as T
+import state_bounds as T
 import rerevst_oracle as O
 pkg = importlib.import_module("rerevst-code_amd")
 hip = pkg.Stylization(pkg.synthetic_weights(0), cuda=True)
@@ -24,3 +24,47 @@ for case in ("global_a", "global_b"):
     ep = np.abs(p - rp); bp = T.PRE_ATOL + T.PRE_RTOL * np.abs(rp)
     print("%s: state worst entry at %.0f%% of its bound (%s) | pre-clamp max|d| %.2e (worst err/bound %.3f, ref std %.3f) | image max|d| %.4f grey levels (bound %.2f)"
           % (case, 100 * sworst, swhere, ep.max(), (ep / bp).max(), rp.std(), np.abs(o - ro).max(), T.IMG_ATOL))
+hip.close()
+
+
+def report(case, got_state, ref_state, pre, ref_pre, out, ref_out, extra=""):
+    sworst, swhere = T.state_worst(got_state, ref_state)
+    pw, pmax = T.pre_worst(pre, ref_pre)
+    print("%s: state worst entry at %.0f%% of its bound (%s) | pre-clamp max|d| %.2e (worst err/bound %.3f, ref std %.3f) | image max|d| %.4f grey levels (bound %.2f)%s"
+          % (case, 100 * sworst, swhere, pmax, pw, ref_pre.std(), np.abs(out - ref_out).max(), T.IMG_ATOL, extra))
+
+
+# round 3: the reference's own inputs
+g = T.load_golden("real_default")
+hip = pkg.Stylization(pkg.synthetic_weights(0), cuda=True)
+hip.prepare_style(T.decode_png(g["style_png"])); hip.clean()
+for i in g["sample_ids"]: hip.add(T.decode_png(g["frame%d_png" % int(i)]))
+hip.compute()
+out = hip.transfer(O.reflect_pad(T.decode_png(g["frame%d_png" % int(g["transfer_id"])]), 576, 1152))[64:500, 64:1088]
+pre = hip.preclamp(576, 1152)[64:500, 64:1088]
+report("real_default (plum_flower 400x564, ambush_4 436x1024, B=5)", hip.get_state(), g["state"], pre[::4, ::4], g["pre_grid"], out[::4, ::4], g["out_grid"],
+       " | dense 64x64 patch: pre %.2e, image %.4f" % (np.abs(pre[186:250, 480:544] - g["pre_patch"]).max(), np.abs(out[186:250, 480:544] - g["out_patch"]).max()))
+g = T.load_golden("img1_256")
+frame = T.decode_png(g["frame_png"])
+hip.prepare_style(T.decode_png(g["style_png"])); hip.clean(); hip.add(frame); hip.compute()
+out = hip.transfer(O.reflect_pad(frame, 384, 384))[64:320, 64:320]
+pre = hip.preclamp(384, 384)[64:320, 64:320]
+report("img1_256 (data/img_1.jpg, one 256x256 frame, B=1)", hip.get_state(), g["state"], pre[::2, ::2], g["pre_grid"], out[::2, ::2], g["out_grid"])
+hip.close()
+# round 3: further weight sets
+for v in ("seed1", "dead", "dec4"):
+    g = T.load_golden("global_a_" + v)
+    style, frames, ids, tid = T.golden_inputs(pkg, g)
+    hip = pkg.Stylization(pkg.weight_variant(v), cuda=True)
+    hip.prepare_style(style); hip.clean()
+    for i in ids: hip.add(frames[i])
+    hip.compute()
+    st = hip.get_state()
+    extra = ""
+    if v == "dec4":
+        mine, _ = T.state_worst(st, g["state_fp64"]); theirs, _ = T.state_worst(g["state"], g["state_fp64"])
+        extra = " | ill-conditioned: distance to the float64 reference state %.1fx the bound (the reference's own float32 run: %.1fx); image/pre-clamp below with the REFERENCE state" % (mine, theirs)
+        hip.set_state(g["state"])
+    out = hip.transfer(O.reflect_pad(frames[tid], 192, 192)); pre = hip.preclamp(192, 192)
+    report("global_a_" + v, st, g["state"], pre, g["pre"], out, g["out"], extra)
+    hip.close()
