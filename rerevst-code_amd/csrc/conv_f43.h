@@ -1,0 +1,530 @@
+// conv_f43.h — Winograd F(4x4,3x3) 3x3 convolution on the fp32 matrix cores: 36 multiplies per 4x4 outputs instead of
+// 144 (the F(2x2,3x3) kernel of conv_wino_split.h needs 64), for the same-resolution 3x3 layers with Cin, Cout >= 64
+// (vgg19.features convs, test/style_network_global.py:271-281; ResidualBlock.conv2 :104,119-122).
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A,   6x6 patches four pixels apart, interpolation points 0, +-1, +-2, inf
+//
+// Why this form fits the machine where "36 positions x 32 couts x 16 channels" does not:
+//  * one wave per SIMD (4 waves, 512 registers each): a wave owns 16 tiles (8 x 32 output pixels) x 32 output channels
+//    x all 36 positions = 288 accumulator registers (AGPRs + a few VGPRs), so the input transform is amortised over
+//    two 16-cout blocks: ONE packed VALU op per MFMA;
+//  * 8-channel chunks: v_mfma_f32_16x16x4_f32 twice per (position, cout block); the transformed patch of a lane is
+//    36 x 2 floats (its tile, channel pair 2q, 2q+1) and IS the B operand — it never touches LDS;
+//  * the four waves of a workgroup share one U block (36 x 32 couts x 8 channels = 36 KB) and one 34 x 34 halo
+//    (40 KB), both double buffered by buffer_load ... lds: 154 KB of LDS, one workgroup per CU;
+//  * a work item = 32 x 32 output pixels x 32 output channels; persistent workgroups walk the items as one stream
+//    (the last two chunks of an item request the next item's first tiles, as in conv_wino_k).
+//
+// LDS images (all ds_read_b64, conflict free in each 32-lane group):
+//  raw : [halo row y 0..33][x & 3][x >> 2 (0..8)][32 B = 4 slots of one channel pair]; slot = pair ^ 2*((y>>2)&1):
+//        a read of patch piece (dy, dx) by the 16 tiles (2 x 8) x 2 pairs of a lane group covers 256 distinct bytes
+//  U   : [position 0..35][cout row 0..31][32 B]; slot = pair ^ 2*((row>>3)&1)
+#pragma once
+#include "conv_wino.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct F43Geo {
+    static constexpr int NT = 256;                              // 4 waves, one per SIMD
+    static constexpr int NPOS = 36;
+    static constexpr int RAW_ROW_BYTES = 4 * 9 * 32;            // 1152: 4 column phases x 9 column groups x 32 B
+    static constexpr int RAW_PIECES = 34 * 4 * 9 * 2;           // 16-byte pieces (2448; 2312 of them are halo pixels)
+    static constexpr int RAW_IT = (RAW_PIECES + NT - 1) / NT;   // 10 LDS-DMA instructions per thread
+    static constexpr int RAW_BYTES = RAW_IT * NT * 16;          // 40960
+    static constexpr int U_BYTES = NPOS * 32 * 8 * 4;           // 36864 per (cout slab, chunk)
+    static constexpr int U_IT = U_BYTES / 16 / NT;              // 9
+    static constexpr int SMEM = 2 * RAW_BYTES + 2 * U_BYTES + WINO_PAR_BYTES;     // 157 696 B
+};
+
+// ---- packed fp32 helpers (v_pk_* through inline asm: the compiler has no packed form for constants / subtractions)
+__device__ __forceinline__ f32x2 p2add(const f32x2 a, const f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 p2sub(const f32x2 a, const f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 p2fma(const f32x2 a, const f32x2 k, const f32x2 c) {      // a * k + c
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(k), "v"(c));
+    return r;
+}
+template <int IMM>
+__device__ __forceinline__ f32x2 lds_rd64(unsigned addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds_read offset is a 16-bit unsigned immediate");
+    f32x2 r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(IMM));
+    return r;
+}
+
+// The 288 accumulators of a wave exceed the 256 AGPRs, and the compiler keeps all MFMA results of a kernel in ONE
+// register file: the MFMAs are therefore issued by inline asm with the accumulator's file pinned per position
+// (positions 0..27 in AGPRs, 28..35 in VGPRs).  Hazards the compiler no longer sees are covered by construction:
+// dependent MFMAs on one accumulator are one independent MFMA apart, operands come from counted s_waitcnt or a chunk
+// earlier, and the epilogue reads the accumulators behind a barrier and explicit s_nops.
+template <bool AG>
+__device__ __forceinline__ void mfma_acc(f32x4& acc, const float a, const float b) {
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <bool AG>
+__device__ __forceinline__ void mfma_zero(f32x4& acc, const float a, const float b) {      // acc = a (x) b
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
+
+// One 1-D input transform B^T (6 -> 6) as TWELVE ops on the lane's channel pair, issued one or two at a time in the
+// gaps between the MFMAs (every instruction of the K loop is a volatile asm: the order written is the order issued).
+// All multipliers are the inline constants +-4, +-2 (the usual -5 is folded away: 4 d0 - 5 d2 + d4 = 4 (d0 - d2) + (d4 - d2)):
+//   0: a = d4 - 4 d2      1: b = d3 - 4 d1      2: c = d4 - d2        3: f = d3 - d1
+//   4: g = d0 - d2        5: d0 = 4 g + c       6: g = d5 - d3        7: d5 = g - 4 f
+//   8: d1 = a + b         9: d2 = a - b        10: d3 = c + 2 f      11: d4 = c - 2 f
+// (t0 = 4 d0 - 5 d2 + d4, t1/t2 = (d4 - 4 d2) +- (d3 - 4 d1), t3/t4 = (d4 - d2) +- 2 (d3 - d1), t5 = 4 d1 - 5 d3 + d5)
+// PK = 1: v_pk_*_f32, one instruction per op (op_sel_hi:[1,0,1] gives both halves the 32-bit inline constant);
+// PK = 0: two plain VALU instructions per op.
+struct F43Tmp { f32x2 a, b, c, f, g; };
+#define F43_FMAK(NAME, KSTR)                                                                                                     \
+    template <int PK>                                                                                                            \
+    __device__ __forceinline__ f32x2 NAME(const f32x2 x, const f32x2 c) { /* x * K + c */                                        \
+        f32x2 r;                                                                                                                 \
+        if constexpr (PK) asm volatile("v_pk_fma_f32 %0, %1, " KSTR ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(c));        \
+        else asm volatile("v_fma_f32 %0, %2, " KSTR ", %4\n\tv_fma_f32 %1, %3, " KSTR ", %5" : "=&v"(r[0]), "=v"(r[1]) : "v"(x[0]), "v"(x[1]), "v"(c[0]), "v"(c[1])); \
+        return r;                                                                                                                \
+    }
+F43_FMAK(t2fma4, "4.0")
+F43_FMAK(t2fmam4, "-4.0")
+F43_FMAK(t2fma2, "2.0")
+F43_FMAK(t2fmam2, "-2.0")
+template <int PK>
+__device__ __forceinline__ f32x2 t2add(const f32x2 x, const f32x2 y) {
+    f32x2 r;
+    if constexpr (PK) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    else asm volatile("v_add_f32 %0, %2, %4\n\tv_add_f32 %1, %3, %5" : "=&v"(r[0]), "=v"(r[1]) : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
+    return r;
+}
+template <int PK>
+__device__ __forceinline__ f32x2 t2sub(const f32x2 x, const f32x2 y) {
+    f32x2 r;
+    if constexpr (PK) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    else asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %5" : "=&v"(r[0]), "=v"(r[1]) : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
+    return r;
+}
+template <int OP, int PK>
+__device__ __forceinline__ void f43_op(F43Tmp& t, f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
+    if constexpr (OP == 0) t.a = t2fmam4<PK>(d2, d4);
+    if constexpr (OP == 1) t.b = t2fmam4<PK>(d1, d3);
+    if constexpr (OP == 2) t.c = t2sub<PK>(d4, d2);
+    if constexpr (OP == 3) t.f = t2sub<PK>(d3, d1);
+    if constexpr (OP == 4) t.g = t2sub<PK>(d0, d2);
+    if constexpr (OP == 5) d0 = t2fma4<PK>(t.g, t.c);
+    if constexpr (OP == 6) t.g = t2sub<PK>(d5, d3);
+    if constexpr (OP == 7) d5 = t2fmam4<PK>(t.f, t.g);
+    if constexpr (OP == 8) d1 = t2add<PK>(t.a, t.b);
+    if constexpr (OP == 9) d2 = t2sub<PK>(t.a, t.b);
+    if constexpr (OP == 10) d3 = t2fma2<PK>(t.f, t.c);
+    if constexpr (OP == 11) d4 = t2fmam2<PK>(t.f, t.c);
+}
+template <int PK>
+__device__ __forceinline__ void f43_in_all(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
+    F43Tmp t;
+    static_for([&](auto oc) { f43_op<decltype(oc)::value, PK>(t, d0, d1, d2, d3, d4, d5); }, std::make_integer_sequence<int, 12>{});
+}
+// SIX independent 1-D transforms (all columns, or all rows, of a patch), op by op in lockstep: the five instructions
+// behind an op never need its result (a dependent packed op would wait ~9 cycles, an independent one issues in ~4).
+// L(n, j) = element j of line n.
+template <int PK, class LineFn>
+__device__ __forceinline__ void f43_in6(LineFn&& L) {
+    F43Tmp t[6];
+    static_for([&](auto oc) {
+        constexpr int op = decltype(oc)::value;
+        static_for([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            f43_op<op, PK>(t[n], L(nc, std::integral_constant<int, 0>{}), L(nc, std::integral_constant<int, 1>{}), L(nc, std::integral_constant<int, 2>{}),
+                           L(nc, std::integral_constant<int, 3>{}), L(nc, std::integral_constant<int, 4>{}), L(nc, std::integral_constant<int, 5>{}));
+        }, std::make_integer_sequence<int, 6>{});
+    }, std::make_integer_sequence<int, 12>{});
+}
+// (superseded) MFMA-loop schedule of the next chunk's transform: iteration i, slot s (the gap behind the s-th MFMA) -> the 1-D
+// transform (columns dx = 0..5, then rows r = 0..5 as 6..11) and the ops [first, first + count) of it.
+// Column pass dx: iterations 4 + 2 dx and 5 + 2 dx, (2, 1, 2, 1) ops per slot; row pass r: iterations 16 + 3 r .. 18 + 3 r, one op per slot.
+struct F43Slot { int line, first, count; };
+constexpr F43Slot f43_slot(int i, int s) {
+    if (i >= 4 && i <= 15) {
+        const int dx = (i - 4) / 2, half = (i - 4) & 1;
+        const int first = half * 6 + (s == 0 ? 0 : s == 1 ? 2 : s == 2 ? 3 : 5);
+        return F43Slot{dx, first, (s & 1) ? 1 : 2};
+    }
+    if (i >= 16 && i <= 33) {
+        const int r = (i - 16) / 3, m = (i - 16) % 3;
+        return F43Slot{6 + r, 4 * m + s, 1};
+    }
+    return F43Slot{-1, 0, 0};
+}
+
+// 1-D output transform A^T (6 -> 4) on a channel pair:
+//   y0 = m0 + (m1 + m2) + (m3 + m4)     y1 = (m1 - m2) + 2 (m3 - m4)     y2 = (m1 + m2) + 4 (m3 + m4)     y3 = (m1 - m2) + 8 (m3 - m4) + m5
+__device__ __forceinline__ void f43_out(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
+                                        f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3) {
+    const f32x2 s1 = t2add<1>(m1, m2), d1 = t2sub<1>(m1, m2), s2 = t2add<1>(m3, m4), d2 = t2sub<1>(m3, m4);
+    y0 = t2add<1>(t2add<1>(m0, s1), s2);
+    y1 = t2fma2<1>(d2, d1);
+    y2 = t2fma4<1>(s2, s1);
+    y3 = t2add<1>(t2fma4<1>(d2, t2fma4<1>(d2, d1)), m5);      // 8 is no inline constant: 4 d2 + (4 d2 + d1)
+}
+
+template <int EPI, int ABL = 0, int PK = 0>
+__global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
+    using G = F43Geo;
+    constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, NT = G::NT, NPOS = G::NPOS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, t = lane & 15, q = lane >> 4;
+    const int tr = t >> 3, tc = t & 7;           // the wave's 16 tiles: 2 rows x 8 columns of 4x4 outputs = 8 x 32 pixels
+    const int nchunks = p.Cin >> 3;              // 8-channel chunks; even and >= 4 (Cin a multiple of 16, >= 32)
+    const int n_ntiles = p.Cout >> 5;
+
+    // ---- work items (32 x 32 output pixels x 32 couts): the same XCD-aware incremental walk as conv_wino_k
+    struct Item { int tx, ty, b, nt; };
+    Item cur, nxt, dlt;
+    {
+        const int GD = gridDim.x, w = blockIdx.x;
+        int pix, dpix;
+        if (p.xcd_slabs) {
+            const int PT = (GD >> 3) / n_ntiles;
+            pix = (w & 7) * PT + (w >> 3) / n_ntiles; dpix = 8 * PT;
+            cur.nt = (w >> 3) % n_ntiles; dlt.nt = 0;
+        } else {
+            cur.nt = w % n_ntiles; pix = w / n_ntiles;
+            dlt.nt = GD % n_ntiles; dpix = GD / n_ntiles;
+        }
+        cur.tx = pix % p.tiles_x; cur.ty = (pix / p.tiles_x) % p.tiles_y; cur.b = pix / (p.tiles_x * p.tiles_y);
+        dlt.tx = dpix % p.tiles_x; dlt.ty = (dpix / p.tiles_x) % p.tiles_y; dlt.b = dpix / (p.tiles_x * p.tiles_y);
+    }
+    auto advance = [&](const Item& a) {
+        Item r = a;
+        r.nt += dlt.nt;
+        int carry = 0;
+        if (r.nt >= n_ntiles) { r.nt -= n_ntiles; carry = 1; }
+        r.tx += dlt.tx + carry;
+        if (r.tx >= p.tiles_x) { r.tx -= p.tiles_x; r.ty += 1; }
+        r.ty += dlt.ty;
+        if (r.ty >= p.tiles_y) { r.ty -= p.tiles_y; r.b += 1; }
+        r.b += dlt.b;
+        return r;
+    };
+    const size_t img_floats = (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
+    auto in_of = [&](const Item& a) {
+        return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * (p.Wi + 2) + (a.tx + p.tx0) * 32) * p.Cin;
+    };
+    // bytes from the item's tile origin to the end of ITS image (ring included): LDS-DMA lanes beyond get zeros, so a
+    // tile that overruns the image's last rows never sees the next image (a frame's arithmetic is the same in any batch)
+    auto lim_of = [&](const Item& a) {
+        const long rows_left = (long)(p.Hi + 2) - (long)(a.ty + p.ty0) * 32;
+        const long n = (rows_left * (p.Wi + 2) - (long)(a.tx + p.tx0) * 32) * p.Cin * 4;
+        return (int)(n > 0x7fffffffL ? 0x7fffffffL : n);
+    };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (U_BYTES / 4); };
+    int asrc[G::RAW_IT];
+#pragma unroll
+    for (int it = 0; it < G::RAW_IT; ++it) {
+        int e = it * NT + tid;
+        if (e >= G::RAW_PIECES) e = 0;
+        const int half = e & 1, xd = (e >> 1) % 9, ph = ((e >> 1) / 9) & 3, y = (e >> 1) / 36;
+        const int x = 4 * xd + ph, par = (y >> 2) & 1;
+        asrc[it] = ((y * (p.Wi + 2) + x) * p.Cin + 4 * (half ^ par)) * 4;
+    }
+    bool have = cur.b < p.B, have_nxt = false;
+    const float* in_t = in_of(cur);
+    const float* w_t = w_of(cur);
+    int lim_t = lim_of(cur);
+    const float* in_n = in_t;
+    const float* w_n = w_t;
+    int lim_n = lim_t;
+    auto stage_u = [&](int chunk) {
+        char* udst = smem + 2 * RAW_BYTES + (chunk & 1) * U_BYTES;
+#pragma unroll
+        for (int it = 0; it < G::U_IT; ++it) bufld16(w_t, udst + (it * NT + wave * 64) * 16, tid * 16, chunk * U_BYTES + it * NT * 16);
+    };
+    auto stage_raw = [&](int chunk) {
+        char* rdst = smem + (chunk & 1) * RAW_BYTES;
+        const rsrc_t rs = make_rsrc(in_t, lim_t);
+#pragma unroll
+        for (int it = 0; it < G::RAW_IT; ++it) bufld16_rs(rs, rdst + (it * NT + wave * 64) * 16, asrc[it], chunk * 32);
+    };
+    char* const par = smem + 2 * RAW_BYTES + 2 * U_BYTES;
+    auto stage_params = [&](int ntile) {
+        if (wave < 2) {
+            const int e = tid;
+            const int row = e >> 3, col = (e & 7) * 4;
+            const float* src = p.bias;
+            int off = ntile * 32 + col;
+            if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off += (EPI & E_NORM1) ? (row - 1) * p.Cout : 0; }
+            if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off += (EPI & E_NORM2) ? (row - 5) * p.Cout : 0; }
+            if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off += (EPI & E_NORM2) ? (row - 9) * p.Cout : 0; }
+            if (row > 10) { src = p.bias; off = ntile * 32; }
+            glds16(src + off, par + wave * 1024);
+        }
+    };
+
+    // ---- LDS read addresses.  Patch piece (dy, dx) of tile (tr, tc): halo row 8 wave + 4 tr + dy, column 4 tc + dx.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int y0 = 8 * wave + 4 * tr;
+    // rows dy 0..3 have (y>>2)&1 == tr&1 (8 wave is even), rows dy 4,5 the opposite parity
+    const unsigned rawA = lds0 + y0 * G::RAW_ROW_BYTES + tc * 32 + ((q ^ (2 * (tr & 1))) << 3);
+    const unsigned rawB = lds0 + y0 * G::RAW_ROW_BYTES + tc * 32 + ((q ^ (2 * ((tr & 1) ^ 1))) << 3);
+    const unsigned offU = lds0 + 2 * RAW_BYTES + t * 32 + ((q ^ (2 * (t >> 3))) << 3);      // cout row t (block 0); block 1 = +512 (same (row>>3)&1)
+
+    const unsigned lane_off = (unsigned)(((4 * tr) * (p.W + 2) + 4 * tc) * p.Cout + 4 * q) * 4u;      // epilogue stores, see there
+    // Positions whose accumulators live in AGPRs: 28 x 2 blocks x 4 = 224 of the 256; positions 28..35 sit in VGPRs, and the
+    // 32 free AGPRs take what the register allocator cannot keep in VGPRs outside the K loops (v_accvgpr moves instead of
+    // scratch reloads, whose s_waitcnt vmcnt(0) would serialise the LDS-DMA stream)
+    constexpr int NAG = 28;
+    f32x4 accA[NAG][2], accV[NPOS - NAG][2];
+    int par_ntile = -1;
+    long long tl[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
+    auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
+    f32x2 v[NPOS];                // transformed patch B^T d B of the chunk in flight: V[r][k] at index k*6 + r (raw piece (dy, dx) at dx*6 + dy)
+    f32x2 ur[2][6][2];            // U fragments of two position batches: [ring slot][r][cout block]
+    auto full_transform = [&](f32x2 (&d)[NPOS]) {
+        // column passes: line dx = d[6 dx + 0..5]; then row passes: line r = d[r], d[6 + r], .., d[30 + r]
+        f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return d[decltype(nc)::value * 6 + decltype(jc)::value]; });
+        f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return d[decltype(jc)::value * 6 + decltype(nc)::value]; });
+    };
+    // patch piece (dy, dx) of the raw tile in raw buffer `RB` (byte offset) -> v[dx*6 + dy]
+    auto read_patch_col = [&](auto rbc, auto dxc) {
+        constexpr int RB = decltype(rbc)::value, dx = decltype(dxc)::value;
+        static_for([&](auto dyc) {
+            constexpr int dy = decltype(dyc)::value;
+            constexpr int off = RB + dy * G::RAW_ROW_BYTES + (dx & 3) * 288 + (dx >> 2) * 32;
+            v[dx * 6 + dy] = lds_rd64<off>(dy < 4 ? rawA : rawB);
+        }, std::make_integer_sequence<int, 6>{});
+    };
+    // U fragments of position batch b (= transform column k = b: positions r*6 + b, r = 0..5) from the U buffer at `ub`
+    auto read_u_batch = [&](unsigned ub, auto bc, auto slotc) {
+        constexpr int b = decltype(bc)::value, sl = decltype(slotc)::value;
+        static_for([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            ur[sl][r][0] = lds_rd64<(r * 6 + b) * 1024>(ub);
+            ur[sl][r][1] = lds_rd64<(r * 6 + b) * 1024 + 512>(ub);
+        }, std::make_integer_sequence<int, 6>{});
+    };
+
+    // One chunk.  On gfx950 the f32 MFMA runs on the vector ALU: NOTHING overlaps it inside a wave — every interruption of
+    // an MFMA run costs ~10 cycles plus ~4 per instruction (tools/mfma_filler_bench) — so with one wave per SIMD the
+    // chunk is SIX uninterrupted runs of 24 MFMAs (position batch b = transform column b, both cout blocks, 8 channels)
+    // and the LDS reads / LDS-DMA requests / input transform are packed into the gaps between them:
+    //   gap b (before run b): wait for U batch b; request U batch b+1; patch column b-1 of the NEXT chunk into the V
+    //                         registers run b-1 has just consumed (V is single buffered); the chunk's LDS-DMA (gaps 1..3)
+    //   tail               : patch column 5; wait; K-loop barrier; request U batch 0 of the next chunk; the whole input
+    //                         transform (144 packed ops, three independent lines in lockstep) covers that latency.
+    // Every instruction of the loop is a volatile asm: the order written is the order issued.
+    auto chunk_body = [&](int c, auto par_c, auto first_c, bool last) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
+        // chunk c requests U(c+1) -> U buffer (c+1)&1 and raw(c+2) -> raw buffer c&1; past the item's end the same
+        // slots carry the NEXT item's U(0), raw(0), raw(1) (nchunks is even)
+        const bool own_u = c + 1 < nchunks, own_r = c + 2 < nchunks;
+        const rsrc_t rs_u = make_rsrc(own_u ? w_t : w_n);
+        const rsrc_t rs_r = make_rsrc(own_r ? in_t : in_n, own_r ? lim_t : lim_n);
+        const int usoff = own_u ? (c + 1) * U_BYTES : 0;
+        const int rsoff = (own_r ? c + 2 : c + 2 - nchunks) * 32;
+        char* const udst = smem + 2 * RAW_BYTES + (1 - PAR) * U_BYTES;
+        char* const rdst = smem + PAR * RAW_BYTES;
+        const unsigned ub = offU + PAR * U_BYTES;          // U buffer c&1
+        const unsigned ubn = offU + (1 - PAR) * U_BYTES;   // U buffer (c+1)&1
+        using RBt = std::integral_constant<int, (1 - PAR) * RAW_BYTES>;      // raw buffer (c+1)&1: the next chunk's patch
+        static_for([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            // ---- gap b: U batch b is needed now; younger LDS reads = the patch column requested in run b-1's mini gap
+            if constexpr (b <= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            if constexpr (b < 5) read_u_batch(ub, std::integral_constant<int, b + 1>{}, std::integral_constant<int, (b + 1) & 1>{});
+            // ---- run b: 24 MFMAs, with ONE mini gap in the middle (a wave may have 15 LDS reads outstanding: the patch column
+            // cannot ride with the 12 U reads) that also carries the chunk's LDS-DMA requests — wave w issues all of its 19 in
+            // run w: the four waves of the CU share one address unit, requests issued at the same time queue behind each other
+            static_for([&](auto rc) {
+                constexpr int r = decltype(rc)::value, pos = r * 6 + b;
+                if constexpr (r == 3) {
+                    if constexpr (b >= 1) { if (!last) read_patch_col(RBt{}, std::integral_constant<int, b - 1>{}); }
+                    if constexpr (b < 4) {
+                        if (!(ABL & 1) && wave == b) {
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < G::RAW_IT; ++i) bufld16_rs(rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
+#pragma unroll
+                            for (int i = 0; i < G::U_IT; ++i) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                constexpr bool AG = pos < NAG;
+                f32x4 (&ac)[2] = *[&]() -> f32x4 (*)[2] { if constexpr (AG) return &accA[pos]; else return &accV[pos - NAG]; }();
+                const f32x2 vv = v[b * 6 + r];
+                f32x2 (&uu)[2] = ur[b & 1][r];
+                if constexpr (FIRST) { mfma_zero<AG>(ac[0], uu[0][0], vv[0]); mfma_zero<AG>(ac[1], uu[1][0], vv[0]); }
+                else { mfma_acc<AG>(ac[0], uu[0][0], vv[0]); mfma_acc<AG>(ac[1], uu[1][0], vv[0]); }
+                mfma_acc<AG>(ac[0], uu[0][1], vv[1]);
+                mfma_acc<AG>(ac[1], uu[1][1], vv[1]);
+            }, std::make_integer_sequence<int, 6>{});
+        }, std::make_integer_sequence<int, 6>{});
+        // ---- tail: the last patch column, the barrier, the next chunk's first U batch, the transform.  The last chunk of
+        // an item only runs the barrier: the next item's patch is read behind the output transform (which needs the
+        // registers), see the item loop.
+        if (!last) read_patch_col(RBt{}, std::integral_constant<int, 5>{});
+        tick(1);
+        if (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tick(3);
+        if (!last) {
+            read_u_batch(ubn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            if (!(ABL & 8)) full_transform(v);
+        }
+        tick(5);
+    };
+
+    // first tiles of an item whose predecessor did not request them (the workgroup's first item)
+    auto next_patch = [&]() {        // the item's raw(0) patch + first U batch -> registers, then V(0)
+        static_for([&](auto dxc) { read_patch_col(std::integral_constant<int, 0>{}, dxc); }, std::make_integer_sequence<int, 6>{});
+        read_u_batch(offU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        // every wave has read raw(0) before any wave's chunk 0 requests raw(2) into the same buffer
+        if (!(ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(ABL & 8)) full_transform(v);
+    };
+    if (have) {
+        stage_raw(0);
+        stage_u(0);
+        stage_raw(1);
+        stage_params(cur.nt);
+        par_ntile = cur.nt;
+        __syncthreads();
+        next_patch();
+    }
+    if (ABL & 16) tl_t = clock64();
+    while (have) {
+        const int e_y0 = (cur.ty + p.ty0) * 32, e_x0 = (cur.tx + p.tx0) * 32, e_b = cur.b, e_ntile = cur.nt;
+        nxt = advance(cur);
+        have_nxt = nxt.b < p.B;
+        in_n = have_nxt ? in_of(nxt) : in_t;
+        w_n = have_nxt ? w_of(nxt) : w_t;
+        lim_n = have_nxt ? lim_of(nxt) : lim_t;
+        if (par_ntile != e_ntile) {
+            __syncthreads();
+            stage_params(e_ntile);
+            par_ntile = e_ntile;
+        }
+        tick(0);                                  // item setup
+        chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, false);
+        chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, false);
+        for (int c = 2; c < nchunks; c += 2) {
+            chunk_body(c, std::integral_constant<int, 0>{}, std::false_type{}, false);
+            chunk_body(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, c + 2 == nchunks);
+        }
+        cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n; lim_t = lim_n;
+        asm volatile("s_nop 15\n\ts_nop 7");       // the last MFMAs' results before any VALU / v_accvgpr_read touches them
+        auto ACC = [&](int i, int nb) -> f32x4 { return i < NAG ? accA[i][nb] : accV[i - NAG][nb]; };
+        if (ABL & 32) {                           // microbench only: no epilogue at all (keeps the accumulators alive)
+            f32x4 s = ACC(0, 0);
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) if (i || nb) s += ACC(i, nb);
+            if (s[0] + s[1] + s[2] + s[3] == 123.456f) p.out[tid] = s[0];
+            if (have) next_patch();
+            continue;
+        }
+        // ---- output transform Y = A^T M A (rows of M = acc[r*6 + k]) + fused epilogue, all in registers
+        const int yb = e_y0 + 8 * wave + 4 * tr, xb = e_x0 + 4 * tc;
+        // Stores: wave-uniform 64-bit base (SGPRs: image, item origin, the wave's rows, pixel (i, j), cout block) + ONE
+        // loop-invariant 32-bit lane offset (the tile inside the wave's 8 x 32 pixels and the lane's 4 couts): no
+        // per-store address arithmetic in vector registers (precomputed addresses would be held across the whole K loop)
+        char* const sb = (char*)(p.out + (size_t)e_b * (size_t)(p.H + 2) * (p.W + 2) * p.Cout +
+                                 ((size_t)(e_y0 + 8 * wave + 1) * (p.W + 2) + e_x0 + 1) * p.Cout + e_ntile * 32);
+        const int rowb = (p.W + 2) * p.Cout * 4, pixb = p.Cout * 4;
+        const bool interior = e_y0 + 32 <= p.H && e_x0 + 32 <= p.W;       // wave-uniform: no per-pixel masks inside the image
+        // Register diet: a 16-cout block is finished in two channel-pair halves — T (6 x 4 pairs) and the first half's 16
+        // output pairs are all that is live besides the next item's V(0) — so nothing spills between the K loops.
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const char* pl = par + (nb * 16 + 4 * q) * 4;
+            f32x2 Y0[4][4];      // [i][j]: channels 0, 1 of the lane's four
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                auto PR = [&](int i) -> f32x2 { const f32x4 a = ACC(i, nb); return hh ? f32x2{a[2], a[3]} : f32x2{a[0], a[1]}; };
+                f32x2 T[6][4];      // T[r][j] = sum_k M[r][k] A^T[j][k]
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    f43_out(PR(r * 6 + 0), PR(r * 6 + 1), PR(r * 6 + 2), PR(r * 6 + 3), PR(r * 6 + 4), PR(r * 6 + 5), T[r][0], T[r][1], T[r][2], T[r][3]);
+                    __builtin_amdgcn_sched_barrier(0);      // accumulators are copied out of the AGPRs row by row, not all up front
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 Y[4];
+                    f43_out(T[0][j], T[1][j], T[2][j], T[3][j], T[4][j], T[5][j], Y[0], Y[1], Y[2], Y[3]);
+                    if (hh == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) Y0[i][j] = Y[i];
+                        continue;
+                    }
+                    const f32x4 bias = *(const f32x4*)(pl);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 o = e4add(f32x4{Y0[i][j][0], Y0[i][j][1], Y[i][0], Y[i][1]}, bias);
+                        if (EPI & E_RELU) o = f4relu(o);
+                        if (EPI & E_LRELU) o = f4lrelu(o);
+                        if (EPI & E_NORM1) o = f4norm_clamp(o, *(const f32x4*)(pl + 128), *(const f32x4*)(pl + 256), *(const f32x4*)(pl + 384), *(const f32x4*)(pl + 512));
+                        char* const dst = sb + (i * rowb + j * pixb + nb * 64);
+                        if (ABL & 4) { if (o[0] == 123.456f) *(float*)(dst + lane_off) = o[0]; }
+                        else if (interior || (yb + i < p.H && xb + j < p.W)) *(f32x4*)(dst + lane_off) = o;
+                    }
+                }
+            }
+        }
+        tick(4);                                  // epilogue issue
+        if (have) next_patch();                   // the next item's raw(0), U(0) landed with the last chunk's barrier
+        tick(5);
+    }
+    if ((ABL & 16) && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.dbg[(blockIdx.x * 4 + wave) * 6 + k] = tl[k];
+    }
+}
+
+// Weight transform U = G g G^T for F(4x4,3x3), packed [Cout/32][Cin/8][position 36][cout row 32][8 floats] with the
+// 8-byte slots of a row XOR-swizzled by 2*((row>>3)&1) (a lane-linear LDS-DMA copy lands as the conflict-free image):
+//   G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+__global__ void pack_f43_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin) {
+    const size_t total = (size_t)Cout * Cin * 36;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int fl = (int)(r & 7); r >>= 3;             // float inside the 32-byte row: slot = fl >> 1
+        const int row = (int)(r & 31); r >>= 5;
+        const int pos = (int)(r % 36); r /= 36;
+        const int nchunks = Cin / 8;
+        const int chunk = (int)(r % nchunks); r /= nchunks;
+        const int n_tile = (int)r;
+        const int pair = (fl >> 1) ^ (2 * ((row >> 3) & 1));
+        const int co = n_tile * 32 + row, ci = chunk * 8 + 2 * pair + (fl & 1);
+        const float* g = w + ((size_t)co * Cin + ci) * 9;
+        const int pr = pos / 6, pc = pos % 6;
+        auto G3 = [](int rw, float g0, float g1, float g2) -> float {
+            switch (rw) {
+                case 0: return 0.25f * g0;
+                case 1: return (-1.f / 6.f) * (g0 + g1 + g2);
+                case 2: return (-1.f / 6.f) * (g0 - g1 + g2);
+                case 3: return (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+                case 4: return (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+                default: return g2;
+            }
+        };
+        float rowv[3];   // (G g)[pr][kx]
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) rowv[kx] = G3(pr, g[0 * 3 + kx], g[1 * 3 + kx], g[2 * 3 + kx]);
+        dst[i] = G3(pc, rowv[0], rowv[1], rowv[2]);
+    }
+}

@@ -284,7 +284,7 @@ def test_two_frame_sizes_alternate_without_reallocating(hip, pkg, oracle):
     """Two workspace geometries stay resident per slot: alternating between two frame sizes gives the same bits as
     running each size alone, and a third size evicts only the least recently used one."""
     a = oracle.reflect_pad(pkg.synth_frame(910, 40, 56, kind="smooth"), 128, 128)
-    b = oracle.reflect_pad(pkg.synth_frame(911, 90, 50, kind="smooth"), 192, 128)
+    b = oracle.reflect_pad(pkg.synth_frame(911, 60, 50, kind="smooth"), 192, 128)
     c = oracle.reflect_pad(pkg.synth_frame(912, 24, 24, kind="smooth"), 64, 64)
     ra, rb, rc = hip.transfer(a), hip.transfer(b), hip.transfer(c)
     hip.debug_fail_alloc(1)              # from here on ANY device allocation would fail ...

@@ -140,7 +140,7 @@ def test_streaming_compute_equals_resident_and_reference(pkg, weights, oracle):
     assert info1[0] == len(ids) and info1[1] == 1
     assert_state_close(st1, res, "streaming G=1 vs resident")
     assert_state_close(st1, g["state"], "streaming G=1 vs reference")
-    st2, info2 = run((info1[2] + info[2]) // 2)           # room for two of the three frames: groups of 2, the last one ragged
+    st2, info2 = run(info[2] - 1)                        # just below the resident workspace: room for two of the three frames (+ frame 0's copy and residuals), the last group ragged
     assert info2[1] == 2 and info2[0] == 2
     assert_state_close(st2, res, "streaming G=2 vs resident")
     # the per-frame path with the streamed state

@@ -1,4 +1,9 @@
-// conv_wino_split.h — Winograd F(2x2,3x3) 3x3 convolution, 8 waves, transform rows split inside wave pairs.
+// tools/conv_wino_split_ab.h — MICROBENCHMARK copy of rerevst-code_amd/csrc/conv_wino_split.h with the ablation switches
+// (ABL: 1 no LDS-DMA after the first stage, 2 no K-loop barriers, 4 no stores, 8 / 128 s_setprio experiments, 16 per-phase
+// clock64 timeline into p.dbg, 32 no epilogue, 64 no residual loads).  conv_wino_split_ab_k<EPI, 0> compiles to the
+// same instruction stream as the library kernel conv_wino_split_k<EPI> (compared with llvm-objdump when the copy was made).
+//
+// (original header:) Winograd F(2x2,3x3) 3x3 convolution, 8 waves, transform rows split inside wave pairs.
 //
 // Same layers, work items, LDS staging and item stream as conv_wino_k<.., UPS = 0> (conv_wino.h; reference:
 // vgg19.features convs, test/style_network_global.py:271-281; ResidualBlock.conv2 :104,119-122; KernelFilter
@@ -18,31 +23,11 @@
 // (max-pool layers need all four pixels of a tile in one lane: wave `half` finishes channel block `half` and gets
 // the partner's two row sums of that block instead — the same four vectors, the epilogue stays balanced).
 #pragma once
-#include "conv_wino.h"
+#include "../rerevst-code_amd/csrc/conv_wino_split.h"
 
-#define WSPLIT_XCH_BYTES 32768          /* exchange: 8 waves x 4 vectors x 64 lanes x 16 B */
-#define WSPLIT_SMEM_BYTES (WinoGeo<8, 0>::SMEM + WSPLIT_XCH_BYTES)   /* 146 KB */
 
-// c = a * s + b on the packed-fp32 pipe
-__device__ __forceinline__ f32x4 f4fma(const f32x4 a, const float s, const f32x4 b) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 sv = {s, s};
-    f32x2 lo, hi;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(sv), "v"(__builtin_shufflevector(b, b, 0, 1)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(sv), "v"(__builtin_shufflevector(b, b, 2, 3)));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
-
-struct WSplitSched {
-    // MFMA-loop iteration i (= local position, 0..7): first up to three patch pieces, then the U fragments of
-    // position i+2.  LDS returns in order, so U(i) complete => everything issued before it is complete.
-    static constexpr int pieces_in(int i) { return (i >= 0 && i < 4) ? 3 : 0; }
-    static constexpr int issued(int i) { return pieces_in(i) + (i + 2 < 8 ? 2 : 0); }
-    static constexpr int younger(int i) { return i == 0 ? 2 + issued(0) : issued(i - 1) + issued(i); }
-};
-
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void conv_wino_split_ab_k(const ConvP p) {
     using G = WinoGeo<8, 0>;
     using S = WSplitSched;
     constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, U_LDS = G::U_LDS, NT = G::NT;
@@ -54,6 +39,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     const int tg = wave >> 1;                    // tile group: output rows 4*tg .. 4*tg+3 of the workgroup tile
     const int half = wave & 1;                   // transform rows {0,1} / {3,2}; finishes output row `half` of each tile
     const float sgn = half ? -1.f : 1.f;
+    if ((ABL & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);       // microbench: static priority for the second-dispatched half
+    if ((ABL & 128) && half) __builtin_amdgcn_s_setprio(1);          // microbench: priority for one wave of every pair
     const int nchunks = p.Cin >> 4;              // even
     const int cs = p.cstride ? p.cstride : p.Cin;    // channels per pixel in memory (split K: the launch contracts a slice of them)
     const int n_ntiles = p.Cout >> 5;
@@ -201,8 +188,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                 asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(d[3 * (i - 2) + 0]), "+v"(d[3 * (i - 2) + 1]), "+v"(d[3 * (i - 2) + 2]), "+v"(u[i & 3][0]), "+v"(u[i & 3][1]) : "i"(S::younger(i)));
             else lds_release2<S::younger(i)>(u[i & 3][0], u[i & 3][1]);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i < G::U_IT) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
-            if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
+            if (!(ABL & 1)) {
+                if constexpr (i < G::U_IT) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
+                if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
+            }
             const f32x4 vv = vcur[(i & 3) * 2 + (i >> 2)];
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -217,6 +206,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
 
     // ---- persistent loop over (pixel tile, cout slab) work items; only the first item has a prologue (see conv_wino_k)
     int par_ntile = -1;
+    long long tl[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
+    auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
+    if (ABL & 16) tl_t = clock64();
     if (have) {
         stage_raw(0);
         stage_u(0);
@@ -251,7 +243,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         const int yb = e_y0 + 4 * tg + 2 * tr, xb = e_x0 + 2 * tc;
         const int y = yb + half;                  // the output row this wave finishes (no-pool layers)
         f32x4 resv[2][2];                         // [nb][j]
-        if (EPI & (E_RES | E_RES_UPS)) {
+        if ((ABL & 64) && (EPI & (E_RES | E_RES_UPS))) {      // microbench only: no residual loads
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) resv[nb][0] = resv[nb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (EPI & (E_RES | E_RES_UPS)) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -263,17 +258,29 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                         resv[nb][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + nb * 16 + 4 * q);
                 }
         }
+        tick(0);                                  // item setup (+ previous epilogue's tail)
         chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb);
-        __syncthreads();          // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
+        if (!(ABL & 2)) __syncthreads();          // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
+        tick(5);                                  // first chunk incl. its barrier (pipeline refill shows up here)
         chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
-        __syncthreads();
+        if (!(ABL & 2)) __syncthreads();
         for (int c = 2; c < nchunks; c += 2) {
             chunk_body(c, std::integral_constant<int, 0>{}, std::false_type{}, va, vb);
-            __syncthreads();
+            if (!(ABL & 2)) __syncthreads();
             chunk_body(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
-            __syncthreads();
+            if (!(ABL & 2)) __syncthreads();
         }
         cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;
+        tick(1);                                  // K loop
+        if (ABL & 32) {                           // microbench only: no epilogue at all (keeps the accumulators alive)
+            f32x4 t = acc[0][0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) if (i || nb) t += acc[i][nb];
+            if (t[0] + t[1] + t[2] + t[3] == 123.456f) p.out[tid] = t[0];
+            continue;
+        }
 
         // ---- output transform: row sums of the wave's two rows, partner's row through LDS, fused epilogue
         f32x4 T[2][2][2];                         // [rl][j][nb]: T'[r][j] = sum_k M[r][k] A[k][j]
@@ -298,7 +305,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) *(f32x4*)(mine + (j * 2 + nb) * 1024) = T[1][j][nb];
         }
+        tick(2);                                  // row sums + exchange writes
         __syncthreads();
+        tick(4);                                  // exchange barrier
         auto finish = [&](const f32x4 Yv, const f32x4& bias, const f32x4& m1, const f32x4& r1, const f32x4& lo1, const f32x4& hi1) {
             f32x4 v = e4add(Yv, bias);
             if (EPI & E_RELU) v = f4relu(v);
@@ -342,7 +351,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                         }
                     }
                     const int y2 = yb >> 1, x2 = xb >> 1;
-                    if (y2 < Ho && x2 < Wo) *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
+                    if (y2 < Ho && x2 < Wo) {
+                        if (ABL & 4) { if (pooled[0] == 123.456f) out_b[co] = pooled[0]; }
+                        else *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
+                    }
                 }
             } else {
                 const char* theirs = xch + (wave ^ 1) * 4096 + lane * 16;
@@ -354,9 +366,18 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                     f32x4 o = finish(Y, bias, m1, r1, lo1, hi1);
                     if (EPI & (E_RES | E_RES_UPS)) o = e4add(o, resv[nb][j]);
                     if (EPI & E_NORM2) o = e4fma(f4norm_clamp(o, m2, r2, lo2, hi2), sstd, smean);
-                    if (y < p.H && x < p.W) *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
+                    if (y < p.H && x < p.W) {
+                        if (ABL & 4) { if (o[0] == 123.456f) out_b[co] = o[0]; }
+                        else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
+                    }
                 }
             }
         }
+        tick(3);                                  // barrier + reads + epilogue issue
+    }
+    if ((ABL & 16) && lane == 0) {
+        long long* dbg = p.dbg;   // microbench only
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dbg[(blockIdx.x * 8 + wave) * 6 + k] = tl[k];
     }
 }

@@ -1,0 +1,71 @@
+// tools/fetch_calib.hip — what rocprofv3's FETCH_SIZE counts for the access patterns of this library.
+// MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports HALF the bytes of a wide coalesced streaming read (128-byte
+// requests tallied at 64 B) and says other widths are uncalibrated.  The transform-domain kernels stage their input by
+// buffer_load_dwordx4 ... lds in 64-byte segments (four lanes = the 16 channels of one pixel's chunk) that are
+// Cin * 4 bytes apart, so the factor must be measured for THAT pattern before FETCH_SIZE is turned into bytes.
+// Every kernel below reads a known number of bytes exactly once from a buffer larger than the Infinity Cache:
+//   stream      : float4 per lane, 1 KB contiguous per wave (the guide's case)
+//   seg64_sNNN  : LDS-DMA, 16 B per lane, 64-byte segments NNN bytes apart (256 = 64-channel tensors, 512, 1024, 2048)
+//   seg256      : LDS-DMA, 256-byte segments (conv_last_k's reads of a 64-channel pixel)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/fetch_calib.hip -o tools/bin/fetch_calib
+//   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out -o p -- tools/bin/fetch_calib ; python tools/fetch_calib_summary.py <db>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../rerevst-code_amd/csrc/conv_mfma.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void stream_k(const float4* __restrict__ in, float* out, size_t n4) {
+    float4 s = {0, 0, 0, 0};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = in[i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (s.x + s.y + s.z + s.w == 123.456f) out[0] = s.x;
+}
+
+// every wave-instruction fetches 64 lanes x 16 B; lane l reads segment (l / LPS) of the instruction, piece l % LPS.
+// Segment j of the whole launch starts at j * STRIDE bytes and only its first SEG bytes are ever read.
+template <int SEG, int STRIDE>
+__global__ __launch_bounds__(256) void seg_k(const char* __restrict__ in, float* out, size_t nseg) {
+    __shared__ __attribute__((aligned(16))) char lds[4096];
+    constexpr int LPS = SEG / 16;                  // lanes per segment
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const size_t seg_per_inst = 64 / LPS;
+    const size_t n_inst = nseg / seg_per_inst;
+    for (size_t it = blockIdx.x * 4 + wave; it < n_inst; it += (size_t)gridDim.x * 4) {
+        const char* base = in + it * seg_per_inst * STRIDE;           // wave-uniform 64-bit base, 32-bit lane offset
+        bufld16(base, lds + wave * 1024, (lane / LPS) * STRIDE + (lane % LPS) * 16, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (((const float*)lds)[threadIdx.x] == 123.456f) out[0] = 1.f;
+}
+
+template <int SEG, int STRIDE>
+void run_seg(const char* buf, float* out, size_t bytes) {
+    const size_t nseg = bytes / STRIDE;
+    hipLaunchKernelGGL((seg_k<SEG, STRIDE>), dim3(2048), dim3(256), 0, 0, buf, out, nseg);
+    CK(hipDeviceSynchronize());
+    printf("seg_k<%d,%d>: %zu segments, %zu useful bytes\n", SEG, STRIDE, nseg, nseg * SEG);
+}
+
+int main() {
+    const size_t bytes = (size_t)2 << 30;          // 2 GiB: eight times the Infinity Cache
+    char* buf; float* out;
+    CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(buf, 0, bytes));
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(stream_k, dim3(4096), dim3(256), 0, 0, (const float4*)buf, out, bytes / 16);
+    CK(hipDeviceSynchronize());
+    printf("stream_k: %zu useful bytes\n", bytes);
+    run_seg<64, 256>(buf, out, bytes);
+    run_seg<64, 512>(buf, out, bytes);
+    run_seg<64, 1024>(buf, out, bytes);
+    run_seg<64, 2048>(buf, out, bytes);
+    run_seg<256, 256>(buf, out, bytes);
+    run_seg<32, 256>(buf, out, bytes);
+    run_seg<32, 512>(buf, out, bytes);
+    return 0;
+}

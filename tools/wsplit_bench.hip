@@ -8,7 +8,7 @@
 #include <math.h>
 #include "../rerevst-code_amd/csrc/conv_mfma.h"
 #include "../rerevst-code_amd/csrc/conv_wino.h"
-#include "../rerevst-code_amd/csrc/conv_wino_split.h"
+#include "conv_wino_split_ab.h"
 #include "../rerevst-code_amd/csrc/prep_kernels.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -22,13 +22,13 @@ float run(ConvP p, int iters, long long* dbg = nullptr) {
     int items = p.tiles_x * p.tiles_y * p.B * slabs;
     dim3 grid(items < 256 ? items : 256, 1);
     p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
-    CK(hipFuncSetAttribute((const void*)conv_wino_split_k<EPI, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES));
+    CK(hipFuncSetAttribute((const void*)conv_wino_split_ab_k<EPI, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((conv_wino_split_k<EPI, ABL>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, p);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((conv_wino_split_ab_k<EPI, ABL>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_split_k<EPI, ABL>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_wino_split_ab_k<EPI, ABL>), grid, dim3(512), WSPLIT_SMEM_BYTES, 0, p);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
