@@ -373,7 +373,7 @@ def main():
         nW = len(feats)
         def step(i):
             ks = [(i * B + j) % nW for j in range(B)]    # position in the shard; global frame index -> the reference's weight ramp
-            model.transfer_many([feats[k] for k in ks], [video.ramp_weights(my_ids[k], NF, NS) for k in ks], out=h_out[i & 1])
+            model.transfer_many([feats[k] for k in ks], [video.ramp_weights(my_ids[k], NF, NS, blend="all") for k in ks], out=h_out[i & 1])
     else:
         n_batches = max(1, min(max(1, nshard // B), args.steps))      # distinct batches kept resident in host memory
         my_ids = [first + i % nshard for i in range(n_batches * B)]
@@ -428,7 +428,7 @@ def main():
                     for k in range(NS):
                         o.per_style[k].set_state(blobs[k])
                     # the encoder pass is the caching step (outside the metric): it runs in make_input, the clock sees the decoder
-                    return (lambda k: o.generate_content_features(frame_of(k))), (lambda f: o.transfer(f, video.ramp_weights(7, NF, NS)))
+                    return (lambda k: o.generate_content_features(frame_of(k))), (lambda f: o.transfer(f, video.ramp_weights(7, NF, NS, blend="all")))
                 cpu = cpu_baseline(setup, "frames/s", "cached relu4_1 features of padded %dx%d frames, %d-style blended decoder" % (P, P, NS))
             else:
                 def setup(O):
@@ -436,8 +436,8 @@ def main():
                     o.set_state(blobs[0])
                     return frame_of, o.transfer
                 cpu = cpu_baseline(setup, "frames/s", "padded %dx%d frames" % (P, P))
-        what = ("%d-frame synthetic %dx%d video (padded %dx%d), %d-style interpolation (decoder only per frame, encoder features "
-                "cached in HBM), frames sharded per GPU" % (NF, S, S, P, P, NS)) if NS else \
+        what = ("%d-frame synthetic %dx%d video (padded %dx%d), %d-style interpolation (every frame blends all %d styles: smooth weight "
+                "ramp; decoder only per frame, encoder features cached in HBM), frames sharded per GPU" % (NF, S, S, P, P, NS, NS)) if NS else \
                ("%d-frame synthetic %dx%d video (padded %dx%d), 1 style, frames sharded per GPU" % (NF, S, S, P, P))
         out = {"metric": "stylized frames/sec at %dx%d, %s" % (S, S, ("%d-style interpolation" % NS) if NS else "1 style"),
                "value": round(world * args.steps * B / dt, 3),
@@ -447,7 +447,7 @@ def main():
                "config": {"workload": what, "entry": ("rrv_transfer_features_batch: relu4_1 features in HBM -> float32 frames in %s host memory" if NS else
                                                       "rrv_transfer_batch: uint8 frames in %s host memory -> float32 frames in the same (H2D + kernels + D2H)")
                                                % ("pageable" if args.pageable else "page-locked"),
-                          "frames_per_step_per_gpu": B, "sub_batch": 1 if NS else max(1, min(32, B, (8 * 640 * 640) // (P * P))), "batches_in_flight": args.pipeline,
+                          "frames_per_step_per_gpu": B, "sub_batch": max(1, min(4, -(-256 // (-(-(P // 8) // 16) ** 2)))) if NS else max(1, min(32, B, (8 * 640 * 640) // (P * P))), "batches_in_flight": args.pipeline,
                           "sampled_frames": len(video.sample_indices_multistyle(NF, 16) if NS else video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
                "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu,
@@ -458,7 +458,10 @@ def main():
                            "slowest_rank": int(np.argmin(rates)), "process_group": (backend if use_dist else None),
                            "rank0_affinity": affinity, "c_abi_rccl_broadcast": c_abi_bcast}
         if NS:
-            out["feature_cache_frames_per_s"] = round(len(feats) / cache_s, 1)
+            fc = len(feats) / cache_s
+            out["feature_cache_frames_per_s"] = round(fc, 1)
+            # a video end to end = the caching pass (encoder, once per frame) THEN the decoder pass: serial rates combine harmonically
+            out["end_to_end_frames_per_s"] = round(1.0 / (1.0 / fc + 1.0 / out["value"]), 1)
         if world == 1 and not args.no_extras and not NS:
             # extras, NOT `value`.  (1) HBM -> HBM on the same frames, 8 per launch, two batches in flight (round 1's headline)
             d_in = torch.from_numpy(np.ascontiguousarray(h_in[0][:16 if B >= 16 else B])).to(dev)
@@ -528,6 +531,28 @@ def main():
                 prev = tk
             model.result(prev)
             out["one_frame_per_call_lookahead_frames_per_s"] = round(n1 / (time.perf_counter() - t1), 1)
+            # (4) zero-copy host I/O (rrv_set_host_io(1)): the first kernel reads the page-locked frames over PCIe, the last one
+            # writes the stylized frames there — no copy kernels, no copy-stream events.  Same frames, same entries.
+            model.set_host_io(1)
+            model.transfer_batch(h_in[0], out=h_out[0])
+            t1 = time.perf_counter()
+            for i in range(nr2):
+                model.transfer_batch(h_in[i % n_batches], out=h_out[i & 1])
+            out["zero_copy_host_frames_per_s"] = round(nr2 * B / (time.perf_counter() - t1), 1)
+            t1 = time.perf_counter()
+            for k in range(n1):
+                model.transfer(one[k])
+            out["zero_copy_one_frame_per_call_frames_per_s"] = round(n1 / (time.perf_counter() - t1), 1)
+            prev = None
+            t1 = time.perf_counter()
+            for k in range(n1):
+                tk = model.transfer_async(one[k])
+                if prev is not None:
+                    model.result(prev)
+                prev = tk
+            model.result(prev)
+            out["zero_copy_one_frame_per_call_lookahead_frames_per_s"] = round(n1 / (time.perf_counter() - t1), 1)
+            model.set_host_io(0)
         if os.environ.get("RRV_BENCH_LAYERS"):
             out["layers"] = [{"layer": k, "ms_per_frame": round(v[1] / nprof / B, 4), "tflops": round(v[2] / v[1] / 1e9, 1),
                               "tflops_executed": round(v[3] / v[1] / 1e9, 1)}

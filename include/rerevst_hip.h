@@ -163,6 +163,11 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* style_weigh
  * two (stream, workspace, blended-state) sets and the D2H copy of one frame overlaps the next frame's kernels. */
 int rrv_transfer_features_batch(rrv_handle h, const int* feature_ids, const float* style_weight, int n, int n_styles, float* out_bgr);
 int rrv_release_features(rrv_handle h);
+/* Frames per launch sequence of rrv_transfer_features_batch (1..4, default 1).  With more than one, every image of a
+ * launch carries its own blended state set (per-image normalisation parameters and folded KernelFilter weights), which
+ * widens the grids of the small relu4_1-level layers; results are bit-identical for every setting.  Measured at
+ * 1152 x 1152 x 4 styles: 340 / 339 / 330 frames/s for 1 / 2 / 4 (the two-stream pipeline already fills the chip). */
+int rrv_set_multistyle_group(rrv_handle h, int frames);
 /* Capacity policy of the feature cache (default 64 GiB).  The reference spills every frame's feature to disk
  * (test.py:87-101, cache/%d.pt), so its video length is unbounded; here a cached feature costs 42 MB of HBM per
  * 1152x1152 frame.  Once the cache would exceed `bytes`, rrv_generate_content_features keeps the frame's uint8 pixels
@@ -188,6 +193,12 @@ int rrv_sync(rrv_handle h);
  * tails overlap the other's kernels.  Callers must give consecutive calls distinct output buffers
  * and call rrv_sync() before reading them.  Host-buffer entries and blend transfers are serialised. */
 int rrv_set_pipeline(rrv_handle h, int n_slots);
+
+/* How the host-buffer entries (rrv_transfer, _batch, _frames, _async) cross PCIe.  0 (default): staged — H2D copy into
+ * HBM, kernels, D2H copy, on dedicated copy streams.  1: zero copy — the first kernel reads the uint8 frames straight
+ * from page-locked host memory and the last one stores the stylized frame there (caller buffers if they are
+ * page-locked, the library's pinned staging otherwise): no copy kernels, no copy-stream events.  Same results bit for bit. */
+int rrv_set_host_io(rrv_handle h, int mode);
 
 /* Stream-ordered use of the *_device entries from a caller that produces / consumes the buffers on its own HIP
  * stream (e.g. torch.cuda.current_stream().cuda_stream): see ORDERING above.  enable = 0 switches it off. */

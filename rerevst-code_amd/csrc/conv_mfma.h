@@ -65,6 +65,12 @@ struct ConvP {
     long long* dbg;    // microbench only (ABL & 16): per-phase cycle counters
     int cstride;       // conv_wino_split_k, split K: channels per pixel of the input tensor (Cin = the slice one "cout slab" contracts); 0: = Cin
     int cin_slab_step; // split K: slab s contracts input channels [s * cin_slab_step, + Cin) and writes output channels [32 s, 32 s + 32) — its partial sum
+    // Per-image state (multi-style interpolation: every frame of a launch has its own blended state, "Multi-style
+    // Interpolation/style_network.py":432-460).  Transform-domain kernels: image b reads its epilogue parameters at
+    // n1 / n2 / sty + b * par_bstride, its bias at bias + b * bias_bstride and its weights at wpk + b * w_bstride
+    // (floats; all 0 = one state / one weight set for the whole launch).
+    int par_bstride, bias_bstride;
+    long long w_bstride;
 };
 
 template <int BN>

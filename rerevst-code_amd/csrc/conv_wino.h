@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     auto in_of = [&](const Item& a) {
         return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)(((a.ty + p.ty0) * G::TIN) * (p.Wi + 2) + (a.tx + p.tx0) * G::TIN) * p.Cin;
     };
-    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NPU * 32 * 16); };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NPU * 32 * 16) + (size_t)a.b * p.w_bstride; };
     int asrc[G::RAW_IT];
 #pragma unroll
     for (int it = 0; it < G::RAW_IT; ++it) {
@@ -268,16 +268,17 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     // per-channel epilogue parameters of the item's cout slab, parked in LDS while the K loop runs:
     // rows of 32 floats: 0 bias | 1-4 n1 (mean, rstd, lo, hi) | 5-8 n2 | 9-10 style mean, std
     char* const par = smem + 2 * RAW_BYTES + 2 * U_LDS;
-    auto stage_params = [&](int ntile) {
+    auto stage_params = [&](int ntile, int img) {      // img: the item's image (per-image state: p.par_bstride)
         if (wave < 2) {
             const int e = tid;                       // 16-byte piece: row e>>3, floats 4*(e&7)..
             const int row = e >> 3, col = (e & 7) * 4;
             const float* src = p.bias;
-            int off = ntile * 32 + col;
-            if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off += (EPI & E_NORM1) ? (row - 1) * p.Cout : 0; }
-            if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off += (EPI & E_NORM2) ? (row - 5) * p.Cout : 0; }
-            if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off += (EPI & E_NORM2) ? (row - 9) * p.Cout : 0; }
-            if (row > 10) { src = p.bias; off = ntile * 32; }
+            const int pb = img * p.par_bstride;
+            int off = ntile * 32 + col + img * p.bias_bstride;
+            if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off = (EPI & E_NORM1) ? ntile * 32 + col + pb + (row - 1) * p.Cout : off; }
+            if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 5) * p.Cout : off; }
+            if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 9) * p.Cout : off; }
+            if (row > 10) { src = p.bias; off = ntile * 32 + img * p.bias_bstride; }
             glds16(src + off, par + wave * 1024);
         }
     };
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     // ---- persistent loop over (pixel tile, cout slab) work items.  Only the first item has a prologue: the last
     // two chunks of every item request the next item's U(0), raw(0), raw(1), and the last chunk body, which reads
     // and transforms "the next chunk's" patch, thereby leaves V(0) of the next item in va.
-    int par_ntile = -1;
+    int par_ntile = -1, par_img = -1;
     long long tl[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
     auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
     if (ABL & 16) tl_t = clock64();
@@ -407,8 +408,8 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         stage_raw(0);
         stage_u(0);
         stage_raw(1);
-        stage_params(cur.nt);
-        par_ntile = cur.nt;
+        stage_params(cur.nt, cur.b);
+        par_ntile = cur.nt; par_img = cur.b;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NPIECE; ++k) va[k] = *(const f32x4*)(smem + (offD[k] - lds0));
@@ -423,10 +424,10 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         have_nxt = nxt.b < p.B;
         in_n = have_nxt ? in_of(nxt) : in_t;      // no next item: the last two chunks re-request this item's first tiles
         w_n = have_nxt ? w_of(nxt) : w_t;         // (valid memory, free LDS buffers, nobody reads them)
-        if (par_ntile != e_ntile) {            // (never re-staged when gridDim.x is a multiple of the slab count)
+        if (par_ntile != e_ntile || ((p.par_bstride | p.bias_bstride) && par_img != e_b)) {      // (never re-staged when gridDim.x is a multiple of the slab count and the state is shared)
             __syncthreads();                       // slower waves may still read the old slab's parameters
-            stage_params(e_ntile);                 // lands before the first K-loop barrier
-            par_ntile = e_ntile;
+            stage_params(e_ntile, e_b);            // lands before the first K-loop barrier
+            par_ntile = e_ntile; par_img = e_b;
         }
         tick(0);                              // zero acc (+ previous epilogue tail)
         chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb);

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * cs + (size_t)(((a.ty + p.ty0) * 16) * (p.Wi + 2) + (a.tx + p.tx0) * 16) * cs +
                (size_t)a.nt * p.cin_slab_step;
     };
-    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (16 * 32 * 16); };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (16 * 32 * 16) + (size_t)a.b * p.w_bstride; };
     int asrc[G::RAW_IT];
 #pragma unroll
     for (int it = 0; it < G::RAW_IT; ++it) {     // same LDS image of the 18x18 halo as conv_wino_k (even/odd column split)
@@ -124,16 +124,17 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     // 0 bias | 1-4 n1 (mean, rstd, lo, hi) | 5-8 n2 | 9-10 style mean, std
     char* const par = smem + 2 * RAW_BYTES + 2 * U_LDS;
     char* const xch = par + WINO_PAR_BYTES;
-    auto stage_params = [&](int ntile) {
+    auto stage_params = [&](int ntile, int img) {      // img: the item's image (per-image state: p.par_bstride)
         if (wave < 2) {
             const int e = tid;
             const int row = e >> 3, col = (e & 7) * 4;
             const float* src = p.bias;
-            int off = ntile * 32 + col;
-            if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off += (EPI & E_NORM1) ? (row - 1) * p.Cout : 0; }
-            if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off += (EPI & E_NORM2) ? (row - 5) * p.Cout : 0; }
-            if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off += (EPI & E_NORM2) ? (row - 9) * p.Cout : 0; }
-            if (row > 10) { src = p.bias; off = ntile * 32; }
+            const int pb = img * p.par_bstride;
+            int off = ntile * 32 + col + img * p.bias_bstride;
+            if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off = (EPI & E_NORM1) ? ntile * 32 + col + pb + (row - 1) * p.Cout : off; }
+            if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 5) * p.Cout : off; }
+            if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 9) * p.Cout : off; }
+            if (row > 10) { src = p.bias; off = ntile * 32 + img * p.bias_bstride; }
             glds16(src + off, par + wave * 1024);
         }
     };
@@ -216,13 +217,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     };
 
     // ---- persistent loop over (pixel tile, cout slab) work items; only the first item has a prologue (see conv_wino_k)
-    int par_ntile = -1;
+    int par_ntile = -1, par_img = -1;
     if (have) {
         stage_raw(0);
         stage_u(0);
         stage_raw(1);
-        stage_params(cur.nt);
-        par_ntile = cur.nt;
+        stage_params(cur.nt, cur.b);
+        par_ntile = cur.nt; par_img = cur.b;
         __syncthreads();
         f32x4 d[12];
 #pragma unroll
@@ -238,10 +239,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         have_nxt = nxt.b < p.B;
         in_n = have_nxt ? in_of(nxt) : in_t;      // no next item: the last two chunks re-request this item's first tiles
         w_n = have_nxt ? w_of(nxt) : w_t;         // (valid memory, free LDS buffers, nobody reads them)
-        if (par_ntile != e_ntile) {            // (never re-staged when gridDim.x is a multiple of the slab count)
+        if (par_ntile != e_ntile || ((p.par_bstride | p.bias_bstride) && par_img != e_b)) {      // (never re-staged when gridDim.x is a multiple of the slab count and the state is shared)
             __syncthreads();                       // slower waves may still read the old slab's parameters
-            stage_params(e_ntile);                 // lands before the first K-loop barrier
-            par_ntile = e_ntile;
+            stage_params(e_ntile, e_b);            // lands before the first K-loop barrier
+            par_ntile = e_ntile; par_img = e_b;
         }
         // output geometry of this item; the residual values are requested NOW so that their HBM latency lies under the K loop
         const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;

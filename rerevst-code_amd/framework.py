@@ -243,6 +243,10 @@ class Stylization():
         they wait for what is queued on it and it waits for their output — no host synchronisation needed."""
         self._chk(self._lib.rrv_set_caller_stream(self._h, C.c_void_p(stream_ptr), 1 if enable else 0))
 
+    def set_host_io(self, mode):
+        """0 (default): staged H2D / D2H copies; 1: zero copy — kernels read / write page-locked host memory directly."""
+        self._chk(self._lib.rrv_set_host_io(self._h, int(mode)))
+
     def set_pipeline(self, n_slots):
         """1: every device-entry call runs on one stream; 2 (default): consecutive calls alternate over two
         (stream, workspace) pairs so two independent batches are in flight."""
@@ -355,6 +359,10 @@ class MultiStyleStylization(Stylization):
 
     def release_features(self):
         self._chk(self._lib.rrv_release_features(self._h))
+
+    def set_multistyle_group(self, frames):
+        """Frames per launch sequence of transfer_many (1..4): per-image blended state inside one launch."""
+        self._chk(self._lib.rrv_set_multistyle_group(self._h, int(frames)))
 
     def set_feature_cache_cap(self, nbytes):
         """Features are cached in HBM up to `nbytes` (default 64 GiB); beyond that a frame is kept as uint8 pixels and

@@ -46,17 +46,23 @@ def sample_indices_multistyle(frame_num, interval=16):
     return [s * interval for s in range((frame_num - 1) // interval + 1)] + [frame_num - 1]
 
 
-def ramp_weights(i, frame_num, n_styles=2):
+def ramp_weights(i, frame_num, n_styles=2, blend="pair"):
     """Per-frame style weights of the multi-style driver loop (test.py:127-131): for two styles exactly the
-    reference's [w, 1-w] with w = i/(frame_num-1).  For more styles the same ramp is chained through the styles
-    in reverse order (the reference ramps from style 1 towards style 0): the video starts on the last style and
-    ends on style 0, blending two neighbouring styles at a time; weights always sum to 1."""
+    reference's [w, 1-w] with w = i/(frame_num-1).  The reference only ever ramps TWO styles; for more this build chains
+    the same ramp through the styles in reverse order (the reference ramps from style 1 towards style 0): the video
+    starts on the last style and ends on style 0.  blend="pair": two neighbouring styles at a time (piecewise linear);
+    blend="all": a smooth partition of unity (normalised Gaussian bumps of width 1.5 styles around the same position),
+    so EVERY style has a non-zero weight in every frame — what bench.py's 4-style configuration uses.  Weights sum to 1."""
     w = i / (frame_num - 1.0) if frame_num > 1 else 1.0
     if n_styles == 1:
         return [1.0]
     if n_styles == 2:
         return [w, 1.0 - w]
     pos = (1.0 - w) * (n_styles - 1)           # 0 -> style 0, n_styles-1 -> the last style
+    if blend == "all":
+        b = [float(np.exp(-((pos - k) / 1.5) ** 2)) for k in range(n_styles)]
+        t = sum(b)
+        return [v / t for v in b]
     lo = min(int(pos), n_styles - 2)
     f = pos - lo
     out = [0.0] * n_styles

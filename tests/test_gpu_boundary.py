@@ -285,7 +285,7 @@ def test_two_frame_sizes_alternate_without_reallocating(hip, pkg, oracle):
     running each size alone, and a third size evicts only the least recently used one."""
     a = oracle.reflect_pad(pkg.synth_frame(910, 40, 56, kind="smooth"), 128, 128)
     b = oracle.reflect_pad(pkg.synth_frame(911, 60, 50, kind="smooth"), 192, 128)
-    c = oracle.reflect_pad(pkg.synth_frame(912, 24, 24, kind="smooth"), 64, 64)
+    c = oracle.reflect_pad(pkg.synth_frame(912, 24, 24, kind="smooth"), 192, 192)
     ra, rb, rc = hip.transfer(a), hip.transfer(b), hip.transfer(c)
     hip.debug_fail_alloc(1)              # from here on ANY device allocation would fail ...
     try:
@@ -390,3 +390,32 @@ def test_bench_nccl_process_group_at_world_size_one():
     pr = j["per_rank"]
     assert pr["process_group"] == "nccl" and len(pr["frames_per_s"]) == 1 and pr["min"] == pr["max"] > 0
     assert pr["c_abi_rccl_broadcast"].startswith("ok") and "bit-identical" in pr["c_abi_rccl_broadcast"], pr
+
+
+def test_zero_copy_host_io_equals_staged(hip, pkg, oracle):
+    """rrv_set_host_io(1): the kernels read the frames from / write the results to page-locked host memory directly
+    (no H2D / D2H copies).  Every host entry gives the same bits as the staged mode: page-locked and pageable caller
+    arrays, ragged sub-batches, the pad / crop entry, one frame per call, look-ahead tickets."""
+    frames = np.stack([oracle.reflect_pad(pkg.synth_frame(950 + i, 40, 56, kind="noise"), 128, 128) for i in range(19)])
+    raw = np.stack([pkg.synth_frame(970 + i, 67, 33, kind="noise") for i in range(5)])
+    ref, ref_raw = hip.transfer_batch(frames), hip.transfer_frames(raw)
+    hip.set_host_io(1)
+    try:
+        np.testing.assert_array_equal(hip.transfer_batch(frames), ref)                  # pageable in / out
+        pin_in = pkg.pinned_empty(frames.shape, np.uint8)
+        pin_in[...] = frames
+        pin_out = pkg.pinned_empty(ref.shape, np.float32)
+        pin_out[...] = -1.0
+        hip.transfer_batch(pin_in, out=pin_out)                                          # page-locked in / out: no staging at all
+        np.testing.assert_array_equal(pin_out, ref)
+        np.testing.assert_array_equal(hip.transfer_batch(pin_in), ref)                  # mixed
+        np.testing.assert_array_equal(hip.transfer_frames(raw), ref_raw)
+        np.testing.assert_array_equal(hip.transfer(frames[7]), ref[7])
+        tickets = [hip.transfer_async(frames[k]) for k in range(6)]
+        for k in (5, 0, 3, 1, 2, 4):
+            np.testing.assert_array_equal(hip.result(tickets[k]), ref[k])
+        t = hip.transfer_async(pin_in[9], out=pin_out[0])
+        np.testing.assert_array_equal(hip.result(t), ref[9])
+    finally:
+        hip.set_host_io(0)
+    np.testing.assert_array_equal(hip.transfer_batch(frames), ref)

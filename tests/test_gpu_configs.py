@@ -140,10 +140,30 @@ def test_streaming_compute_equals_resident_and_reference(pkg, weights, oracle):
     assert info1[0] == len(ids) and info1[1] == 1
     assert_state_close(st1, res, "streaming G=1 vs resident")
     assert_state_close(st1, g["state"], "streaming G=1 vs reference")
-    st2, info2 = run(info[2] - 1)                        # just below the resident workspace: room for two of the three frames (+ frame 0's copy and residuals), the last group ragged
-    assert info2[1] == 2 and info2[0] == 2
+    # groups of two with a ragged last one need five frames here: at this tiny geometry frame 0's copy, its residuals and
+    # the tensors' tile slack cost more than a third frame, so with three frames "two per group" never beats "all resident"
+    frames5 = list(frames) + [pkg.synth_frame(20 + i, *frames[0].shape[:2], kind="smooth") for i in range(2)]
+    def run5(cap):
+        s.clean()
+        s.set_workspace_cap(cap)
+        for f in frames5:
+            s.add(f)
+        s.compute()
+        return s.get_state(), s.last_compute_info()
+    res, info = run5(1 << 40)
+    assert info[0] == 1 and info[1] == 5
+    lo, hi = 1, info[2]                                    # bisect the smallest cap whose groups hold two frames
+    while hi - lo > 1024:
+        mid = (lo + hi) // 2
+        if run5(mid)[1][1] >= 2:
+            hi = mid
+        else:
+            lo = mid
+    st2, info2 = run5(hi)
+    assert info2[1] == 2 and info2[0] == 3 and info2[2] <= hi < info[2]
     assert_state_close(st2, res, "streaming G=2 vs resident")
     # the per-frame path with the streamed state
+    st1b, _ = run(1)                                      # back to the golden's three frames, streamed
     out = s.transfer(oracle.reflect_pad(frames[tid], 192, 192))
     assert np.abs(out - g["out"]).max() <= IMG_ATOL
     s.close()
@@ -196,6 +216,13 @@ def test_multistyle_batched_transfer_equals_per_frame(pkg, weights, oracle):
     assert s.transfer_many(feats, wts, out=pin) is pin
     np.testing.assert_array_equal(pin, single)
     np.testing.assert_array_equal(s.transfer_many(feats[:1], wts[:1])[0], single[0])
+    wall = [V.ramp_weights(i, 7, 4, blend="all") for i in range(7)]       # every style active in every frame
+    single_all = np.stack([s.transfer(feats[i], wall[i]) for i in range(7)])
+    for grp in (2, 3, 4):       # several frames per launch, each image with its own blended state set: same bits (7 = ragged last group)
+        s.set_multistyle_group(grp)
+        np.testing.assert_array_equal(s.transfer_many(feats, wts), single)
+        np.testing.assert_array_equal(s.transfer_many(feats, wall), single_all)
+    s.set_multistyle_group(1)
     one = pkg.Stylization.transfer(s, frames[1])                       # plain transfer: style 0's own state again
     ref0 = pkg.Stylization.transfer(s, frames[1], style_weight=[1.0, 0.0, 0.0, 0.0])
     assert np.abs(one - ref0).max() <= 1e-3

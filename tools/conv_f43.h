@@ -1,4 +1,8 @@
-// conv_f43.h — Winograd F(4x4,3x3) 3x3 convolution on the fp32 matrix cores: 36 multiplies per 4x4 outputs instead of
+// tools/conv_f43.h — PROTOTYPE, not part of the library (DESIGN.md §4 "F(4x4,3x3): built, measured, not shipped"):
+// it wins 1.08-1.22x over the shipped F(2x2,3x3) kernel (profiles/r03_f43_bench.txt) and costs 3-6x the rounding error
+// — on the reference's default input it would put the pre-clamp error at 1.35x the stated bound (profiles/r03_f43_numerics.txt).
+//
+// Winograd F(4x4,3x3) 3x3 convolution on the fp32 matrix cores: 36 multiplies per 4x4 outputs instead of
 // 144 (the F(2x2,3x3) kernel of conv_wino_split.h needs 64), for the same-resolution 3x3 layers with Cin, Cout >= 64
 // (vgg19.features convs, test/style_network_global.py:271-281; ResidualBlock.conv2 :104,119-122).
 //
@@ -20,7 +24,7 @@
 //        a read of patch piece (dy, dx) by the 16 tiles (2 x 8) x 2 pairs of a lane group covers 256 distinct bytes
 //  U   : [position 0..35][cout row 0..31][32 B]; slot = pair ^ 2*((row>>3)&1)
 #pragma once
-#include "conv_wino.h"
+#include "../rerevst-code_amd/csrc/conv_wino.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

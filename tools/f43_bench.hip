@@ -1,4 +1,4 @@
-// tools/f43_bench.hip — the F(4x4,3x3) kernel (rerevst-code_amd/csrc/conv_f43.h) against a scalar CPU convolution, and
+// tools/f43_bench.hip — the F(4x4,3x3) prototype kernel (tools/conv_f43.h) against a scalar CPU convolution, and
 // its rate next to the shipped F(2x2,3x3) row-split kernel on the layers it would replace, with ablations.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/f43_bench.hip -o tools/bin/f43_bench
 #include <hip/hip_runtime.h>
@@ -9,7 +9,7 @@
 #include "../rerevst-code_amd/csrc/conv_mfma.h"
 #include "../rerevst-code_amd/csrc/conv_wino.h"
 #include "conv_wino_split_ab.h"
-#include "../rerevst-code_amd/csrc/conv_f43.h"
+#include "conv_f43.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -171,11 +171,11 @@ static void bench(const char* name, int B, int H, int W, int Cin, int Cout) {
     std::vector<long long> h((size_t)g * 4 * 6);
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
     double s6[6] = {0};
-    for (size_t i = 0; i < h.size(); ++i) s6[i % 6] += h[i] / 3.0;       // run43 launches the kernel 2 + 1 times: the counters of the last launch overwrite, so no division... (see below)
+    for (size_t i = 0; i < h.size(); ++i) s6[i % 6] += h[i];              // (every launch overwrites the counters: these are the last launch's)
     const double ipw = (double)items / g;
     const char* nm[6] = {"item setup", "MFMA runs + gaps", "-", "barriers", "output transform + stores", "input transforms (+ next item's patch)"};
     printf("     timeline (clk/item, %d chunks = %d MFMA clk):", Cin / 8, Cin / 8 * 4608);
-    for (int k : {0, 1, 3, 5, 4}) printf(" %s %.0f |", nm[k], 3.0 * s6[k] / (g * 4) / ipw);
+    for (int k : {0, 1, 3, 5, 4}) printf(" %s %.0f |", nm[k], s6[k] / (g * 4) / ipw);
     printf(" %.1f items/WG\n", ipw);
     CK(hipFree(dbg));
     free_layer(L);

@@ -3,8 +3,9 @@
     python tools/pmc_summary.py db1 [db2 ...]
 Each counter is summed over its hardware instances per dispatch, then averaged over the
 dispatches of a kernel name.  FETCH_SIZE/WRITE_SIZE are KiB per the tool's definition; on gfx950
-FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM) -> column
-fetch_x2_MB applies that correction."""
+FETCH_SIZE tallies 128-byte requests at 64 B (MI355X_MICROARCH.md §HBM): it is HALF the bytes of >= 128-byte
+contiguous reads (column fetch_x2_MB) but EXACT for the 64-byte-segment LDS-DMA of the transform-domain kernels
+(column fetch_MB; calibration: profiles/r03_fetch_size_calibration.txt, tools/fetch_calib.hip)."""
 import sqlite3
 import sys
 from collections import defaultdict

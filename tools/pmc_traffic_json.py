@@ -1,9 +1,16 @@
 #!/usr/bin/env python
-"""Turn the FETCH_SIZE / WRITE_SIZE rocprofv3 --pmc passes into profiles/hbm_traffic.json:
-    python tools/pmc_traffic_json.py <fetch.db> <write.db> "<bench command the passes ran>" > profiles/hbm_traffic.json
-Per kernel name: average HBM bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (FETCH_SIZE is KiB and
-under-reports wide coalesced reads by 2x on gfx950: MI355X_MICROARCH.md §HBM).  bench.py reads this file to
-fill roofline.traffic for its dominant kernel (PMC counters cannot be collected inside the timed run)."""
+"""Turn the FETCH_SIZE / WRITE_SIZE rocprofv3 --pmc passes into profiles/hbm_traffic_<cfg>.json:
+    python tools/pmc_traffic_json.py <fetch.db> <write.db> "<bench command the passes ran>" > profiles/hbm_traffic_512.json
+Per kernel name: average fabric-side bytes per launch = F * FETCH_SIZE*1024 + WRITE_SIZE*1024.  FETCH_SIZE is KiB and on
+gfx950 tallies 128-byte requests at 64 B (MI355X_MICROARCH.md §HBM), so what it means depends on the access pattern —
+calibrated here with tools/fetch_calib.hip (profiles/r03_fetch_size_calibration.txt: every kernel reads a known byte count
+once from a 2 GiB buffer):
+    contiguous >= 128 B per request (float4 streaming, 256-byte LDS-DMA segments)   FETCH_SIZE = 0.5 x bytes  ->  F = 2
+    64-byte segments (the transform-domain kernels' LDS-DMA: 16 channels of a pixel)   FETCH_SIZE = 1.0 x bytes  ->  F = 1
+    32-byte segments                                                                   FETCH_SIZE = 2.0 x bytes  ->  F = 0.5
+(rounds 1-2 applied F = 2 to every kernel, which doubled the read side of the Winograd kernels: the "1.46x traffic" of
+the dominant kernel was this artefact — with F = 1 it reads 1.27x its input (halo rows) and moves 1.09x its algorithmic bytes.)
+bench.py reads this file to fill roofline.traffic for its dominant kernel (PMC counters cannot be collected inside the timed run)."""
 import json
 import sqlite3
 import sys
@@ -21,15 +28,23 @@ def per_kernel(path, counter):
     return {n: (sum(v) / len(v), len(v)) for n, v in agg.items()}
 
 
+def fetch_factor(name):
+    """Bytes per FETCH_SIZE byte for the kernel's read pattern (see the module docstring)."""
+    if name.startswith(("void conv_wino_k", "void conv_wino_split_k", "void conv_f43_k", "void conv_mfma_k")):
+        return 1.0          # LDS-DMA of 16-channel chunks: 64-byte segments
+    return 2.0              # conv_last_k (256-byte pixels), conv_first_k, streaming float4 kernels, blit copies
+
+
 def main(fetch_db, write_db, cmd):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     out = {"source": {"fetch": fetch_db, "write": write_db, "command": cmd,
-                      "formula": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, averaged over launches"},
+                      "formula": "bytes = (F*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, averaged over launches; F = 1 for the 64-byte-segment "
+                                 "LDS-DMA kernels, 2 for >= 128-byte contiguous reads (profiles/r03_fetch_size_calibration.txt)"},
            "kernels": {}}
     for n in sorted(set(f) | set(w)):
-        fb = 2 * f.get(n, (0, 0))[0] * 1024
+        fb = fetch_factor(n) * f.get(n, (0, 0))[0] * 1024
         wb = w.get(n, (0, 0))[0] * 1024
-        out["kernels"][n] = {"bytes_per_launch": round(fb + wb), "read_bytes": round(fb), "write_bytes": round(wb),
+        out["kernels"][n] = {"bytes_per_launch": round(fb + wb), "read_bytes": round(fb), "write_bytes": round(wb), "fetch_factor": fetch_factor(n),
                              "launches": f.get(n, w.get(n))[1]}
     print(json.dumps(out, indent=1))
 
