@@ -522,15 +522,19 @@ def main():
             for k in range(n1):
                 model.transfer(one[k])
             out["one_frame_per_call_frames_per_s"] = round(n1 / (time.perf_counter() - t1), 1)
-            prev = None
-            t1 = time.perf_counter()
-            for k in range(n1):
-                tk = model.transfer_async(one[k])
-                if prev is not None:
-                    model.result(prev)
-                prev = tk
-            model.result(prev)
-            out["one_frame_per_call_lookahead_frames_per_s"] = round(n1 / (time.perf_counter() - t1), 1)
+            def lookahead(depth):
+                q = []
+                t1 = time.perf_counter()
+                for k in range(n1):
+                    q.append(model.transfer_async(one[k]))
+                    if len(q) > depth:
+                        model.result(q.pop(0))
+                while q:
+                    model.result(q.pop(0))
+                return round(n1 / (time.perf_counter() - t1), 1)
+            lookahead(3)
+            out["one_frame_per_call_lookahead_frames_per_s"] = lookahead(3)       # three frames submitted ahead of the one collected
+            out["one_frame_per_call_lookahead1_frames_per_s"] = lookahead(1)
             # (4) zero-copy host I/O (rrv_set_host_io(1)): the first kernel reads the page-locked frames over PCIe, the last one
             # writes the stylized frames there — no copy kernels, no copy-stream events.  Same frames, same entries.
             model.set_host_io(1)
@@ -543,15 +547,6 @@ def main():
             for k in range(n1):
                 model.transfer(one[k])
             out["zero_copy_one_frame_per_call_frames_per_s"] = round(n1 / (time.perf_counter() - t1), 1)
-            prev = None
-            t1 = time.perf_counter()
-            for k in range(n1):
-                tk = model.transfer_async(one[k])
-                if prev is not None:
-                    model.result(prev)
-                prev = tk
-            model.result(prev)
-            out["zero_copy_one_frame_per_call_lookahead_frames_per_s"] = round(n1 / (time.perf_counter() - t1), 1)
             model.set_host_io(0)
         if os.environ.get("RRV_BENCH_LAYERS"):
             out["layers"] = [{"layer": k, "ms_per_frame": round(v[1] / nprof / B, 4), "tflops": round(v[2] / v[1] / 1e9, 1),

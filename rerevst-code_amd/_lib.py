@@ -56,6 +56,7 @@ SYMBOLS = {
     "rrv_sync": (C.c_int, [C.c_void_p]),
     "rrv_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_set_host_io": (C.c_int, [C.c_void_p, C.c_int]),
+    "rrv_set_grid_share": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_set_caller_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rrv_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "rrv_host_free": (C.c_int, [C.c_void_p]),

@@ -158,6 +158,7 @@ struct rrv_ctx {
     // its set) retires it; `out` / `out_bytes` = where a pageable caller buffer still has to be filled from pin_out
     struct Ticket { long id = -1; float* out = nullptr; size_t out_bytes = 0; bool open = false; } tickets[4];
     long next_ticket = 0;
+    int grid_share = 1;               // rrv_set_grid_share: persistent grids use 1/grid_share of the CUs
     int ms_group = 1;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
     int host_io = 0;                  // rrv_set_host_io: 0 = staged H2D / D2H copies, 1 = zero copy (kernels read / write page-locked host memory)
     int n_cus = 256;
@@ -457,7 +458,8 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (wino) {   // persistent workgroups (one per CU; two for the upsample-fused form), walking tiles_x*tiles_y*B*(Cout/32) work items
         const unsigned slabs = (unsigned)(w.Cout / 32) * ks;
         const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B) * slabs;
-        const unsigned resident = (unsigned)h->n_cus * (c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);
+        unsigned resident = (unsigned)h->n_cus * (c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);
+        if (h->grid_share > 1) resident = (resident / h->grid_share) & ~7u;      // rrv_set_grid_share: leave CUs to the launches of the other stream
         grid = dim3(items < resident ? items : resident, 1);
         // slabs of one pixel tile on one XCD (workgroup w runs on XCD w % 8): the raw tile is fetched once per XCD group
         p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
@@ -1988,15 +1990,12 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
     auto& st = h->hstage[set];
     RCHK(retire_ticket(h, set));                                   // the set's previous ticket (four submissions ago)
     const bool in_pin = is_pinned(frame, fb), out_pin = is_pinned(out, fo * sizeof(float));
-    if (st.cap < fb || st.pcap < fb) {       // (re)size this set: nothing of it is in flight any more
+    if (st.pcap < fb) {       // (re)size this set's page-locked staging: nothing of it is in flight any more
         if (st.d_in) (void)hipFree(st.d_in);
         if (st.d_out) (void)hipFree(st.d_out);
         if (st.pin_in) (void)hipHostFree(st.pin_in);
         if (st.pin_out) (void)hipHostFree(st.pin_out);
         st.d_in = nullptr; st.d_out = nullptr; st.pin_in = nullptr; st.pin_out = nullptr; st.cap = 0; st.pcap = 0;
-        RCHK(dmalloc(h, (void**)&st.d_in, fb));
-        RCHK(dmalloc(h, (void**)&st.d_out, fb * sizeof(float)));
-        st.cap = fb;
         if (hipHostMalloc((void**)&st.pin_in, fb, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void**)&st.pin_out, fb * sizeof(float), hipHostMallocDefault) != hipSuccess)
             return fail(h, RRV_E_NOMEM, "transfer_async: out of page-locked host memory");
@@ -2004,36 +2003,31 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
     }
     const uint8_t* src = frame;
     if (!in_pin) { memcpy(st.pin_in, frame, fb); src = st.pin_in; }
-    const int slot = h->profiling ? 0 : (int)(id & 1) % h->n_slots;
+    // Four tickets may be open: each runs on its own (stream, workspace) with a quarter of the CUs per persistent grid, so
+    // the frames run side by side instead of queueing behind each other's last partial round of work items (one frame
+    // fills 1.56 - 12.5 rounds of 256 workgroups per layer; measured device-resident at 512 x 512, one frame per launch:
+    // 508 frames/s on one stream, 569 on two, 603 on four with a quarter of the CUs each — profiles/r03_b1_streams.txt)
+    const int slot = h->profiling ? 0 : (int)(id % RRV_MAX_SLOTS);
     hipStream_t cs = h->streams[slot];
-    if (h->host_io == 1) {          // zero copy: kernels read `src` and write the destination in page-locked host memory
-        RCHK(ensure_active(h));
-        h->next_slot = slot;
-        const int rc0 = transfer_device(h, src, 1, H, W, out_pin ? out : st.pin_out);
-        h->next_slot = 0;
-        if (rc0 != RRV_OK) return rc0;
-        HIPCHK(hipEventRecord(st.out_done, cs));
-        auto& tk0 = h->tickets[set];
-        tk0.id = id; tk0.out = out_pin ? nullptr : out; tk0.out_bytes = fo * sizeof(float); tk0.open = true;
-        h->next_ticket = id + 1;
-        *ticket = id;
-        return RRV_OK;
+    struct ShareScope { rrv_handle h; int saved; ~ShareScope() { h->grid_share = saved; } } share_scope{h, h->grid_share};
+    if (!h->profiling && h->grid_share == 1) {       // as many shares as frames in flight once this one is queued (1 .. 4)
+        int open = 1;
+        for (auto& tk : h->tickets)
+            if (tk.open && tk.id != id - HOST_SETS && hipEventQuery(h->hstage[tk.id % HOST_SETS].out_done) == hipErrorNotReady) ++open;
+        (void)hipGetLastError();
+        h->grid_share = open > RRV_MAX_SLOTS ? RRV_MAX_SLOTS : open;
     }
-    // d_in / d_out of this set were last used by ticket id-4, retired above (its out_done event has fired)
-    HIPCHK(hipMemcpyAsync(st.d_in, src, fb, hipMemcpyHostToDevice, h->copy_in));
-    HIPCHK(hipEventRecord(st.in_done, h->copy_in));
-    HIPCHK(hipStreamWaitEvent(cs, st.in_done, 0));
+    // Zero copy, whatever rrv_set_host_io says: the first kernel reads `src` and the last one writes the destination in
+    // page-locked host memory.  (Staged copies would add two copy streams to the four compute streams — more streams than
+    // hardware queues, and a D2H copy then waits behind another frame's kernels: measured 230-260 frames/s against 551.)
     RCHK(ensure_active(h));
     h->next_slot = slot;
-    const int rc = transfer_device(h, st.d_in, 1, H, W, st.d_out);
+    const int rc0 = transfer_device(h, src, 1, H, W, out_pin ? out : st.pin_out);
     h->next_slot = 0;
-    if (rc != RRV_OK) return rc;
-    HIPCHK(hipEventRecord(st.k_done, cs));
-    HIPCHK(hipStreamWaitEvent(h->copy_out, st.k_done, 0));
-    HIPCHK(hipMemcpyAsync(out_pin ? (void*)out : (void*)st.pin_out, st.d_out, fo * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
-    HIPCHK(hipEventRecord(st.out_done, h->copy_out));
-    auto& tk = h->tickets[set];
-    tk.id = id; tk.out = out_pin ? nullptr : out; tk.out_bytes = fo * sizeof(float); tk.open = true;
+    if (rc0 != RRV_OK) return rc0;
+    HIPCHK(hipEventRecord(st.out_done, cs));
+    auto& tk0 = h->tickets[set];
+    tk0.id = id; tk0.out = out_pin ? nullptr : out; tk0.out_bytes = fo * sizeof(float); tk0.open = true;
     h->next_ticket = id + 1;
     *ticket = id;
     return RRV_OK;
@@ -2309,6 +2303,12 @@ int rrv_set_pipeline(rrv_handle h, int n_slots) {
     RCHK(sync_all(h));
     h->n_slots = n_slots;
     h->next_slot = 0;
+    return RRV_OK;
+}
+
+int rrv_set_grid_share(rrv_handle h, int share) {
+    if (!h || share < 1 || share > 4) return RRV_E_ARG;
+    h->grid_share = share;
     return RRV_OK;
 }
 

@@ -171,7 +171,8 @@ class Stylization():
             write(framework.result(prev))
 
         overlaps frame i+1's copy-in and kernels with frame i's kernel tails, copy-out and file write.  Up to four
-        tickets may be open.  Same arithmetic as transfer(): bit-identical results."""
+        tickets may be open (each on its own stream with a quarter of the CUs per launch): keeping three frames
+        submitted ahead of the one being collected gives the best rate.  Same arithmetic as transfer(): bit-identical results."""
         if not self.use_Global:
             raise RRVError("transfer_async() needs the global-feature-sharing model (use_Global=True)")
         a = _u8_image(frame, "frame")
@@ -242,6 +243,10 @@ class Stylization():
         """Order the *_device entries against the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream):
         they wait for what is queued on it and it waits for their output — no host synchronisation needed."""
         self._chk(self._lib.rrv_set_caller_stream(self._h, C.c_void_p(stream_ptr), 1 if enable else 0))
+
+    def set_grid_share(self, share):
+        """Persistent grids use 1/share of the CUs (share 1..4): launches of several streams run side by side."""
+        self._chk(self._lib.rrv_set_grid_share(self._h, int(share)))
 
     def set_host_io(self, mode):
         """0 (default): staged H2D / D2H copies; 1: zero copy — kernels read / write page-locked host memory directly."""

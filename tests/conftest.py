@@ -12,7 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 from state_bounds import (PRE_ATOL, PRE_RTOL, IMG_ATOL, STATE_RTOL, STATE_ATOL, NORM_CH, NORM_NAMES, GOLDEN,   # noqa: F401,E402
                           load_golden, decode_png, golden_inputs, state_worst, assert_state_close, assert_pre_close,
-                          pre_worst, assert_state_close_conditioned)
+                          pre_worst, assert_state_close_conditioned, assert_state_close_two_refs)
 
 
 def pytest_configure(config):

@@ -199,16 +199,24 @@ def test_full_size_512_frame_vs_oracle(pkg, oracle, weights):
     s.clean()
     s.add(frames[0])
     s.compute()
-    oracle.set_conv_backend("torch")            # the oracle's convolutions on torch's CPU conv2d: the full-size state in seconds
-    try:
-        oc = oracle.Stylization(weights)
-        oc.prepare_style(style)
-        oc.clean()
-        oc.add(frames[0])
-        oc.compute()
-    finally:
-        oracle.set_conv_backend("numpy")
-    assert_state_close(s.get_state(), oc.get_state(), "512x512, B = 1 state vs oracle")
+    # the full-size state against BOTH float32 restatements of the oracle (nine numpy GEMMs / torch's conv2d).  With one
+    # sampled frame the extrema behind the near-dead relu4_1 channels are ill-conditioned — the two restatements differ by
+    # 35x the regular bound at dec.norm1.max(x)[251] (7.671 / 7.702; the HIP path gives 7.695) — so the HIP state is held
+    # to the restatements' own spread (tests/state_bounds.py); the B = 38 state of the bench is held to the regular bound below
+    refs = []
+    for backend in ("numpy", "torch"):
+        oracle.set_conv_backend(backend)
+        try:
+            oc = oracle.Stylization(weights)
+            oc.prepare_style(style)
+            oc.clean()
+            oc.add(frames[0])
+            oc.compute()
+            refs.append(oc.get_state())
+        finally:
+            oracle.set_conv_backend("numpy")
+    from conftest import assert_state_close_two_refs
+    assert_state_close_two_refs(s.get_state(), refs[0], refs[1], "512x512, B = 1 state vs oracle")
     o = oracle.Stylization(weights)
     o.set_state(s.get_state())
     padded = video.reflect_pad(frames[1], 640, 640)
