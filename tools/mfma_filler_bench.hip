@@ -69,9 +69,70 @@ void run(const char* name, float* out) {
     printf("%-34s x%d per MFMA: %6.1f clk per MFMA slot  (+%5.1f over the bare stream, %4.1f per filler)\n", name, N, per, per - 32.0, N ? (per - 32.0) / N : 0.0);
 }
 
+// Two waves per SIMD (512 threads): every wave repeats [16 MFMAs + 16 N fillers], the fillers either one group of N behind
+// each MFMA (interleaved) or all 16 N behind the 16 MFMAs (batched).  Reports SIMD cycles per MFMA (both waves' MFMAs
+// share the pipe: 32 = the matrix pipe never waits).  PHASE: the odd waves start with the filler block (out of phase).
+template <int KIND, int N, int BATCHED, int PHASE>
+__global__ __launch_bounds__(512, 1) void k2(float* out, int iters) {
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    float a = threadIdx.x * 0.001f, b = 1.0f + threadIdx.x * 0.002f;
+    f32x2 v[8], c = {0.5f, 0.25f};
+    for (int i = 0; i < 8; ++i) v[i] = f32x2{a + i, b + i};
+    const bool odd = (threadIdx.x >> 8) & 1;        // waves 4..7 = the second wave of each SIMD
+    auto fill = [&](int j) {
+        if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(v[j & 7]) : "v"(c));
+        if (KIND == 3) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[j & 7][0]) : "v"(a));
+    };
+    __syncthreads();
+    long long t0 = clock64();
+    if (PHASE && odd) {
+#pragma unroll
+        for (int j = 0; j < 8 * N; ++j) fill(j);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m & 7]) : "v"(a), "v"(b));
+            if (!BATCHED) {
+#pragma unroll
+                for (int f = 0; f < N; ++f) fill(m * N + f);
+            }
+        }
+        if (BATCHED) {
+#pragma unroll
+            for (int j = 0; j < 16 * N; ++j) fill(j);
+        }
+    }
+    long long t1 = clock64();
+    float r = 0;
+    for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][1] + v[i][0] + v[i][1];
+    if (r == 123.456f) out[0] = r;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { ((long long*)out)[2 + 2 * (threadIdx.x >> 6)] = t0; ((long long*)out)[3 + 2 * (threadIdx.x >> 6)] = t1; }
+}
+template <int KIND, int N, int BATCHED, int PHASE>
+void run2(const char* name, float* out) {
+    const int iters = 2000;
+    hipLaunchKernelGGL((k2<KIND, N, BATCHED, PHASE>), dim3(256), dim3(512), 0, 0, out, 200);
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL((k2<KIND, N, BATCHED, PHASE>), dim3(256), dim3(512), 0, 0, out, iters);
+    CK(hipDeviceSynchronize());
+    long long tt[16];
+    CK(hipMemcpy(tt, (char*)out + 16, sizeof tt, hipMemcpyDeviceToHost));
+    long long lo = tt[0], hi = tt[1];
+    for (int w = 0; w < 8; ++w) { if (tt[2 * w] < lo) lo = tt[2 * w]; if (tt[2 * w + 1] > hi) hi = tt[2 * w + 1]; }
+    const double per = (double)(hi - lo) / (iters * 32.0);      // 32 MFMAs per SIMD and iteration; first wave in to last wave out
+    printf("2 waves/SIMD %-26s x%d per MFMA, %-11s%s: %6.1f clk per MFMA of the SIMD (+%5.1f; %4.1f per filler)\n", name, N,
+           BATCHED ? "batched" : "interleaved", PHASE ? ", out of phase" : "", per, per - 32.0, N ? (per - 32.0) / N : 0.0);
+}
+
 int main() {
     float* out;
     CK(hipMalloc(&out, 4096));
+    run2<0, 0, 0, 0>("bare", out);
+    run2<1, 1, 0, 0>("v_pk_fma_f32", out); run2<1, 1, 1, 0>("v_pk_fma_f32", out); run2<1, 1, 1, 1>("v_pk_fma_f32", out);
+    run2<1, 2, 0, 0>("v_pk_fma_f32", out); run2<1, 2, 1, 0>("v_pk_fma_f32", out); run2<1, 2, 1, 1>("v_pk_fma_f32", out);
+    run2<3, 2, 0, 0>("v_fma_f32", out); run2<3, 2, 1, 0>("v_fma_f32", out); run2<3, 2, 1, 1>("v_fma_f32", out);
     run<0, 0>("bare MFMA stream", out);
     run<7, 1>("s_nop 0", out); run<7, 4>("s_nop 0", out);
     run<8, 1>("v_mov_b32", out); run<8, 2>("v_mov_b32", out); run<8, 4>("v_mov_b32", out);
