@@ -1369,7 +1369,17 @@ int rrv_destroy(rrv_handle h) {
         if (kv.second.pk_ups) (void)hipFree(kv.second.pk_ups);
         if (kv.second.pk_ups_sc) (void)hipFree(kv.second.pk_ups_sc);
         if (kv.second.pk_wino) (void)hipFree(kv.second.pk_wino);
+        if (kv.second.bias && kv.second.bias != h->zero_bias) (void)hipFree(kv.second.bias);
     }
+    if (h->zero_bias) (void)hipFree(h->zero_bias);
+    // the state sets live in one allocation per kind; set 0 holds the base pointers (rrv_finalize_weights)
+    for (int f = 0; f < 3; ++f) {
+        const ConvW &fd = h->sets[0].fold_down[f], &fu = h->sets[0].fold_up[f];
+        for (float* q : {fd.raw, fd.bias, fd.pk_wino, fu.raw, fu.pk_wino}) if (q) (void)hipFree(q);
+    }
+    if (h->sets[0].active) (void)hipFree(h->sets[0].active);
+    for (int i = 0; i < 6; ++i) { if (h->fc_w[i]) (void)hipFree(h->fc_w[i]); if (h->fc_b[i]) (void)hipFree(h->fc_b[i]); }
+    if (h->fold_tmp) (void)hipFree(h->fold_tmp);
     for (float* p : h->patches) (void)hipFree(p);
     for (auto& f : h->features) { if (f.p) (void)hipFree(f.p); if (f.u8) (void)hipFree(f.u8); }
     free_plans(h);
