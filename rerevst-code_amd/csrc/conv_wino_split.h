@@ -41,7 +41,9 @@ struct WSplitSched {
     static constexpr int younger(int i) { return i == 0 ? 2 + issued(0) : issued(i - 1) + issued(i); }
 };
 
-template <int EPI>
+// PERIMG = 1: per-image state (ConvP::par_bstride / bias_bstride / w_bstride; the grouped multi-style decoder).  A
+// separate instantiation: the extra scalar state costs the shared-state kernels ~1 % (tools/wsplit_ab2.hip).
+template <int EPI, int PERIMG = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     using G = WinoGeo<8, 0>;
     using S = WSplitSched;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * cs + (size_t)(((a.ty + p.ty0) * 16) * (p.Wi + 2) + (a.tx + p.tx0) * 16) * cs +
                (size_t)a.nt * p.cin_slab_step;
     };
-    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (16 * 32 * 16) + (size_t)a.b * p.w_bstride; };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (16 * 32 * 16) + (PERIMG ? (size_t)a.b * p.w_bstride : (size_t)0); };
     int asrc[G::RAW_IT];
 #pragma unroll
     for (int it = 0; it < G::RAW_IT; ++it) {     // same LDS image of the 18x18 halo as conv_wino_k (even/odd column split)
@@ -129,12 +131,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
             const int e = tid;
             const int row = e >> 3, col = (e & 7) * 4;
             const float* src = p.bias;
-            const int pb = img * p.par_bstride;
-            int off = ntile * 32 + col + img * p.bias_bstride;
+            const int pb = PERIMG ? img * p.par_bstride : 0;
+            int off = ntile * 32 + col + (PERIMG ? img * p.bias_bstride : 0);
             if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off = (EPI & E_NORM1) ? ntile * 32 + col + pb + (row - 1) * p.Cout : off; }
             if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 5) * p.Cout : off; }
             if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 9) * p.Cout : off; }
-            if (row > 10) { src = p.bias; off = ntile * 32 + img * p.bias_bstride; }
+            if (row > 10) { src = p.bias; off = ntile * 32 + (PERIMG ? img * p.bias_bstride : 0); }
             glds16(src + off, par + wave * 1024);
         }
     };
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         v[0 + rl] = f4sub(e0, e2); v[2 + rl] = f4add(e1, e2); v[4 + rl] = f4sub(e2, e1); v[6 + rl] = f4sub(e1, e3);
     };
 
-    auto chunk_body = [&](int c, auto par_c, auto first_c, f32x4 (&vcur)[8], f32x4 (&vnext)[8]) {
+    auto chunk_body = [&](int c, auto par_c, auto first_c, f32x4 (&vcur)[8], f32x4 (&vnext)[8], auto&& hook) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;    // first chunk of an item: accumulators start from zero
         // U(c+1) -> U buffer (c+1)&1, raw(c+2) -> raw buffer c&1; past the end of the item the same slots carry the
@@ -213,7 +215,17 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
             // input transform of the next chunk, sliced under the MFMAs
             if constexpr (i >= 2 && i <= 5) col_pass(d, vnext, i - 2);
             if constexpr (i >= 6) row_pass(vnext, i - 6);
+            hook(ic);
         }, std::make_integer_sequence<int, 8>{});
+    };
+    auto no_hook = [](auto) {};
+    // Barrier behind the item's first chunk: its LDS-DMA must have landed, the residual loads issued AFTER them (in the
+    // same chunk) need not — vector loads return in order, so "at most NRES outstanding" leaves exactly those in flight
+    // (stores of the previous item may still be among the outstanding ones: then even fewer loads are, which is safe).
+    constexpr int NRES = (EPI & E_RES_UPS) ? 2 : (EPI & E_RES) ? 4 : 0;
+    auto barrier_first_chunk = [&]() {
+        if constexpr (NRES) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NRES) : "memory");
+        else __syncthreads();
     };
 
     // ---- persistent loop over (pixel tile, cout slab) work items; only the first item has a prologue (see conv_wino_k)
@@ -239,12 +251,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         have_nxt = nxt.b < p.B;
         in_n = have_nxt ? in_of(nxt) : in_t;      // no next item: the last two chunks re-request this item's first tiles
         w_n = have_nxt ? w_of(nxt) : w_t;         // (valid memory, free LDS buffers, nobody reads them)
-        if (par_ntile != e_ntile || ((p.par_bstride | p.bias_bstride) && par_img != e_b)) {      // (never re-staged when gridDim.x is a multiple of the slab count and the state is shared)
+        if (par_ntile != e_ntile || (PERIMG && par_img != e_b)) {      // (never re-staged when gridDim.x is a multiple of the slab count and the state is shared)
             __syncthreads();                       // slower waves may still read the old slab's parameters
             stage_params(e_ntile, e_b);            // lands before the first K-loop barrier
             par_ntile = e_ntile; par_img = e_b;
         }
-        // output geometry of this item; the residual values are requested NOW so that their HBM latency lies under the K loop
+        // output geometry of this item
         const int Ho = (EPI & E_POOL) ? (p.H >> 1) : p.H, Wo = (EPI & E_POOL) ? (p.W >> 1) : p.W;
         float* out_b = p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout;
         const float* res_b = nullptr;
@@ -252,26 +264,37 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         const int yb = e_y0 + 4 * tg + 2 * tr, xb = e_x0 + 2 * tc;
         const int y = yb + half;                  // the output row this wave finishes (no-pool layers)
         f32x4 resv[2][2];                         // [nb][j]
+        const float* rsrc[2] = {nullptr, nullptr};      // [j]: this lane's residual pixels (channel 4q of the slab's first block)
         if (EPI & (E_RES | E_RES_UPS)) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int x = xb + j;
-                    const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
-                    resv[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (y < p.H && x < p.W)
-                        resv[nb][j] = *(const f32x4*)(res_b + ((ry + 1) * (p.Wr + 2) + rx + 1) * p.Cout + e_ntile * 32 + nb * 16 + 4 * q);
-                }
+            for (int j = 0; j < 2; ++j) {
+                const int x = xb + j;
+                const int ry = (EPI & E_RES_UPS) ? (y >> 1) : y, rx = (EPI & E_RES_UPS) ? (x >> 1) : x;
+                // lanes outside the image read the tensor's first pixel instead (valid memory; their outputs are never stored)
+                const int pix = (y < p.H && x < p.W) ? (ry + 1) * (p.Wr + 2) + rx + 1 : 0;
+                rsrc[j] = res_b + pix * p.Cout + e_ntile * 32 + 4 * q;
+            }
         }
-        chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb);
-        __syncthreads();          // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
-        chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
+        // the residual values are requested behind the first chunk's LDS-DMA instructions (iterations 0..3): the chunk's
+        // barrier does not wait for them (barrier_first_chunk), so their HBM latency has the whole K loop to hide in
+        auto res_hook = [&](auto ic) {
+            if constexpr (decltype(ic)::value == 4 && NRES != 0) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    resv[nb][0] = *(const f32x4*)(rsrc[0] + nb * 16);
+                    if (EPI & E_RES_UPS) resv[nb][1] = resv[nb][0];      // both output columns of a lane lie in ONE low-resolution pixel
+                    else resv[nb][1] = *(const f32x4*)(rsrc[1] + nb * 16);
+                }
+            }
+        };
+        chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb, res_hook);
+        barrier_first_chunk();    // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
+        chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va, no_hook);
         __syncthreads();
         for (int c = 2; c < nchunks; c += 2) {
-            chunk_body(c, std::integral_constant<int, 0>{}, std::false_type{}, va, vb);
+            chunk_body(c, std::integral_constant<int, 0>{}, std::false_type{}, va, vb, no_hook);
             __syncthreads();
-            chunk_body(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va);
+            chunk_body(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va, no_hook);
             __syncthreads();
         }
         cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;

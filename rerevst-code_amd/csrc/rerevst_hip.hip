@@ -357,7 +357,7 @@ void conv_launch(const ConvP& p, dim3 grid, hipStream_t s) {
 
 typedef void (*ConvFn)(const ConvP&, dim3, hipStream_t);
 typedef hipError_t (*AttrFn)();       // per-DEVICE opt-in for > 64 KB of dynamic LDS (run by rrv_create after hipSetDevice)
-struct ConvKey { int BN, TAPS, UPS, EPI; ConvFn fn; const char* name; AttrFn attr; };
+struct ConvKey { int BN, TAPS, UPS, EPI; ConvFn fn; const char* name; AttrFn attr; ConvFn fn_img = nullptr; };   // fn_img: the per-image-state instantiation, where one exists
 #define CK(BN, TAPS, UPS, EPI) {BN, TAPS, UPS, EPI, &conv_launch<BN, TAPS, EPI>, "conv_mfma<" #BN "," #TAPS "," #EPI ">", nullptr}
 const ConvKey CONV_TABLE[] = {
     // 1x1 shortcuts of the residual blocks (evaluated before the upsample)
@@ -377,22 +377,26 @@ template <int EPI, int NW, int UPS, int SC>
 hipError_t wino_attr() {
     return hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<NW, UPS, SC>::SMEM);
 }
-template <int EPI>
+template <int EPI, int PERIMG>
 void wsplit_launch(const ConvP& p, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_wino_split_k<EPI>), grid, dim3(512), WSPLIT_SMEM_BYTES, s, p);
+    hipLaunchKernelGGL((conv_wino_split_k<EPI, PERIMG>), grid, dim3(512), WSPLIT_SMEM_BYTES, s, p);
 }
-template <int EPI>
+template <int EPI, int PERIMG>
 hipError_t wsplit_attr() {
-    return hipFuncSetAttribute((const void*)conv_wino_split_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_split_k<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES);
+    if (e == hipSuccess && PERIMG) e = hipFuncSetAttribute((const void*)conv_wino_split_k<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES);
+    return e;
 }
-#define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI>, "conv_wino<" #EPI ">", &wsplit_attr<EPI>}
+#define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI, 0>, "conv_wino<" #EPI ">", &wsplit_attr<EPI, 0>, nullptr}
+// decoder layers: also instantiated with per-image state (grouped multi-style launches)
+#define WKI(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI, 0>, "conv_wino<" #EPI ">", &wsplit_attr<EPI, 1>, &wsplit_launch<EPI, 1>}
 #define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 0>, "conv_upw<" #EPI ">", &wino_attr<EPI, UPW_NW, 1, 0>}
 #define UWS(EPI) {32, 10, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 1>, "conv_upw_sc<" #EPI ">", &wino_attr<EPI, UPW_NW, 1, 1>}
 const ConvKey WINO_TABLE[] = {
-    WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
-    WK(0),      // raw partial sums of a split-K launch
+    WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WKI(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
+    WKI(0),     // raw partial sums of a split-K launch
     // KernelFilter 32->512 convs with the folded dynamic filter (+ residual, + AdaIN after Filter3)
-    WK(E_RES), WK(E_RES | E_NORM2),
+    WKI(E_RES), WKI(E_RES | E_NORM2),
     // ResidualBlock.conv1 behind the nearest-x2 upsample (forward pass / preparation pass)
     UW(E_LRELU | E_NORM1), UW(E_LRELU),
     // the same with the block's 1x1 shortcut fused in as a tenth position (per-frame path)
@@ -477,6 +481,10 @@ int conv(rrv_handle h, const ConvCall& c) {
                                 (fuse_sc ? (double)c.B * c.in->H * c.in->W * w.Cout + (double)w.Cout * cin : 0.0));
     hipStream_t s = h->stream;
     ConvFn fn = k->fn;
+    if (wino && !c.ups && (c.par_bstride | c.bias_bstride || c.w_bstride)) {      // the row-split kernel carries per-image state in a separate instantiation
+        if (!k->fn_img) return fail(h, RRV_E_ARG, "conv: this layer has no per-image-state kernel");
+        fn = k->fn_img;
+    }
     if (h->profiling) {   // "<kernel>@CinxCout@HxW": bench.py groups by the part before '@'
         char nm[160];
         snprintf(nm, sizeof nm, "%s@%dx%d@%dx%d", k->name, w.Cin, w.Cout, c.H, c.W);

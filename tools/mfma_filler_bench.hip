@@ -80,9 +80,13 @@ __global__ __launch_bounds__(512, 1) void k2(float* out, int iters) {
     f32x2 v[8], c = {0.5f, 0.25f};
     for (int i = 0; i < 8; ++i) v[i] = f32x2{a + i, b + i};
     const bool odd = (threadIdx.x >> 8) & 1;        // waves 4..7 = the second wave of each SIMD
+    int sc[4] = {__builtin_amdgcn_readfirstlane((int)blockIdx.x + 3), 5, 7, 11}, sk = __builtin_amdgcn_readfirstlane(iters | 1);
     auto fill = [&](int j) {
         if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(v[j & 7]) : "v"(c));
         if (KIND == 3) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[j & 7][0]) : "v"(a));
+        if (KIND == 9) asm volatile("s_mul_i32 %0, %0, %1" : "+s"(sc[j & 3]) : "s"(sk));                 // scalar ALU, four independent chains
+        if (KIND == 10) asm volatile("s_add_u32 %0, %0, %1\n\ts_addc_u32 %2, %2, 0" : "+s"(sc[0]), "+s"(sk), "+s"(sc[1]));   // 64-bit add: a dependent pair (counts as 2)
+        if (KIND == 11) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sc[j & 3]) : "v"(a));            // what a spilled SGPR costs
     };
     __syncthreads();
     long long t0 = clock64();
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(512, 1) void k2(float* out, int iters) {
     long long t1 = clock64();
     float r = 0;
     for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][1] + v[i][0] + v[i][1];
+    r += (float)(sc[0] ^ sc[1] ^ sc[2] ^ sc[3] ^ sk);
     if (r == 123.456f) out[0] = r;
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { ((long long*)out)[2 + 2 * (threadIdx.x >> 6)] = t0; ((long long*)out)[3 + 2 * (threadIdx.x >> 6)] = t1; }
 }
@@ -133,6 +138,11 @@ int main() {
     run2<1, 1, 0, 0>("v_pk_fma_f32", out); run2<1, 1, 1, 0>("v_pk_fma_f32", out); run2<1, 1, 1, 1>("v_pk_fma_f32", out);
     run2<1, 2, 0, 0>("v_pk_fma_f32", out); run2<1, 2, 1, 0>("v_pk_fma_f32", out); run2<1, 2, 1, 1>("v_pk_fma_f32", out);
     run2<3, 2, 0, 0>("v_fma_f32", out); run2<3, 2, 1, 0>("v_fma_f32", out); run2<3, 2, 1, 1>("v_fma_f32", out);
+    // scalar work in the shadow of the MFMAs (item bookkeeping): how many SALU instructions per MFMA are free?
+    run2<9, 1, 0, 0>("s_mul_i32", out); run2<9, 2, 0, 0>("s_mul_i32", out); run2<9, 4, 0, 0>("s_mul_i32", out); run2<9, 8, 0, 0>("s_mul_i32", out);
+    run2<9, 12, 0, 0>("s_mul_i32", out); run2<9, 8, 1, 0>("s_mul_i32", out);
+    run2<10, 1, 0, 0>("s_add_u32 + s_addc_u32", out); run2<10, 2, 0, 0>("s_add_u32 + s_addc_u32", out); run2<10, 4, 0, 0>("s_add_u32 + s_addc_u32", out);
+    run2<11, 1, 0, 0>("v_readlane_b32", out); run2<11, 2, 0, 0>("v_readlane_b32", out); run2<11, 4, 0, 0>("v_readlane_b32", out); run2<11, 4, 1, 0>("v_readlane_b32", out);
     run<0, 0>("bare MFMA stream", out);
     run<7, 1>("s_nop 0", out); run<7, 4>("s_nop 0", out);
     run<8, 1>("v_mov_b32", out); run<8, 2>("v_mov_b32", out); run<8, 4>("v_mov_b32", out);
