@@ -326,6 +326,8 @@ def main():
     else:
         model = pkg.Stylization(weights, cuda=True, device=local)
     model.set_pipeline(args.pipeline)
+    if os.environ.get("RRV_BENCH_GRID_SHARE"):       # experiment knob: every launch takes 1/n of the CUs (DESIGN 4 "One frame per call")
+        model.set_grid_share(int(os.environ["RRV_BENCH_GRID_SHARE"]))
 
     # ---- once-per-video preparation on rank 0, state broadcast over RCCL ------------------
     lo, hi = video.shard_range(NF, rank, world)                # this rank's contiguous shard of the video

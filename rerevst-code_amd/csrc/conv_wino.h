@@ -179,7 +179,8 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-template <int EPI, int ABL = 0, int NW = 4, int UPS = 1, int SC = 0>
+// PERIMG = 1: per-image state (ConvP::par_bstride / bias_bstride / w_bstride), a separate instantiation as in conv_wino_split.h
+template <int EPI, int ABL = 0, int NW = 4, int UPS = 1, int SC = 0, int PERIMG = 0>
 __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_wino_k(const ConvP p) {
     static_assert(UPS == 1 && NW == 4, "library kernel: upsample-fused form, 4 waves (other forms: tools/conv_wino_ab.h)");
     static_assert(!(EPI & E_POOL), "no pooling behind an upsample");
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     auto in_of = [&](const Item& a) {
         return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)(((a.ty + p.ty0) * G::TIN) * (p.Wi + 2) + (a.tx + p.tx0) * G::TIN) * p.Cin;
     };
-    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NPU * 32 * 16) + (size_t)a.b * p.w_bstride; };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NPU * 32 * 16) + (PERIMG ? (size_t)a.b * p.w_bstride : (size_t)0); };
     int asrc[G::RAW_IT];
 #pragma unroll
     for (int it = 0; it < G::RAW_IT; ++it) {
@@ -273,12 +274,12 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
             const int e = tid;                       // 16-byte piece: row e>>3, floats 4*(e&7)..
             const int row = e >> 3, col = (e & 7) * 4;
             const float* src = p.bias;
-            const int pb = img * p.par_bstride;
-            int off = ntile * 32 + col + img * p.bias_bstride;
+            const int pb = PERIMG ? img * p.par_bstride : 0;
+            int off = ntile * 32 + col + (PERIMG ? img * p.bias_bstride : 0);
             if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off = (EPI & E_NORM1) ? ntile * 32 + col + pb + (row - 1) * p.Cout : off; }
             if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 5) * p.Cout : off; }
             if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 9) * p.Cout : off; }
-            if (row > 10) { src = p.bias; off = ntile * 32 + img * p.bias_bstride; }
+            if (row > 10) { src = p.bias; off = ntile * 32 + (PERIMG ? img * p.bias_bstride : 0); }
             glds16(src + off, par + wave * 1024);
         }
     };
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         have_nxt = nxt.b < p.B;
         in_n = have_nxt ? in_of(nxt) : in_t;      // no next item: the last two chunks re-request this item's first tiles
         w_n = have_nxt ? w_of(nxt) : w_t;         // (valid memory, free LDS buffers, nobody reads them)
-        if (par_ntile != e_ntile || ((p.par_bstride | p.bias_bstride) && par_img != e_b)) {      // (never re-staged when gridDim.x is a multiple of the slab count and the state is shared)
+        if (par_ntile != e_ntile || (PERIMG && par_img != e_b)) {      // (never re-staged when gridDim.x is a multiple of the slab count and the state is shared)
             __syncthreads();                       // slower waves may still read the old slab's parameters
             stage_params(e_ntile, e_b);            // lands before the first K-loop barrier
             par_ntile = e_ntile; par_img = e_b;

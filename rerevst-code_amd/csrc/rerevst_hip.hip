@@ -368,14 +368,16 @@ const ConvKey CONV_TABLE[] = {
 
 constexpr int WINO_NW = 8;     // waves per Winograd workgroup (conv_wino.h: 8 = two waves per SIMD, one 16-cout block each)
 constexpr int UPW_NW = 4;      // upsample-fused form: 4 waves, 54 KB of LDS, two workgroups per CU
-template <int EPI, int NW, int UPS, int SC>
+template <int EPI, int NW, int UPS, int SC, int PERIMG = 0>
 void wino_launch(const ConvP& p, dim3 grid, hipStream_t s) {
     using Geo = WinoGeo<NW, UPS, SC>;
-    hipLaunchKernelGGL((conv_wino_k<EPI, 0, NW, UPS, SC>), grid, dim3(NW * 64), Geo::SMEM, s, p);
+    hipLaunchKernelGGL((conv_wino_k<EPI, 0, NW, UPS, SC, PERIMG>), grid, dim3(NW * 64), Geo::SMEM, s, p);
 }
-template <int EPI, int NW, int UPS, int SC>
+template <int EPI, int NW, int UPS, int SC, int PERIMG = 0>
 hipError_t wino_attr() {
-    return hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<NW, UPS, SC>::SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS, SC, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<NW, UPS, SC>::SMEM);
+    if (e == hipSuccess && PERIMG) e = hipFuncSetAttribute((const void*)conv_wino_k<EPI, 0, NW, UPS, SC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeo<NW, UPS, SC>::SMEM);
+    return e;
 }
 template <int EPI, int PERIMG>
 void wsplit_launch(const ConvP& p, dim3 grid, hipStream_t s) {
@@ -392,6 +394,7 @@ hipError_t wsplit_attr() {
 #define WKI(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI, 0>, "conv_wino<" #EPI ">", &wsplit_attr<EPI, 1>, &wsplit_launch<EPI, 1>}
 #define UW(EPI) {32, 9, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 0>, "conv_upw<" #EPI ">", &wino_attr<EPI, UPW_NW, 1, 0>}
 #define UWS(EPI) {32, 10, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 1>, "conv_upw_sc<" #EPI ">", &wino_attr<EPI, UPW_NW, 1, 1>}
+#define UWSI(EPI) {32, 10, 1, EPI, &wino_launch<EPI, UPW_NW, 1, 1>, "conv_upw_sc<" #EPI ">", &wino_attr<EPI, UPW_NW, 1, 1, 1>, &wino_launch<EPI, UPW_NW, 1, 1, 1>}
 const ConvKey WINO_TABLE[] = {
     WK(E_RELU), WK(E_RELU | E_POOL), WK(E_RELU | E_NORM1), WKI(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2), WK(E_LRELU),
     WKI(0),     // raw partial sums of a split-K launch
@@ -400,7 +403,7 @@ const ConvKey WINO_TABLE[] = {
     // ResidualBlock.conv1 behind the nearest-x2 upsample (forward pass / preparation pass)
     UW(E_LRELU | E_NORM1), UW(E_LRELU),
     // the same with the block's 1x1 shortcut fused in as a tenth position (per-frame path)
-    UWS(E_LRELU | E_NORM1),
+    UWSI(E_LRELU | E_NORM1),
     // frame mode: raw conv1 output (its statistics are per frame) + fused shortcut
     UWS(E_LRELU),
 };
@@ -481,7 +484,7 @@ int conv(rrv_handle h, const ConvCall& c) {
                                 (fuse_sc ? (double)c.B * c.in->H * c.in->W * w.Cout + (double)w.Cout * cin : 0.0));
     hipStream_t s = h->stream;
     ConvFn fn = k->fn;
-    if (wino && !c.ups && (c.par_bstride | c.bias_bstride || c.w_bstride)) {      // the row-split kernel carries per-image state in a separate instantiation
+    if (wino && (c.par_bstride | c.bias_bstride || c.w_bstride)) {      // per-image state is a separate instantiation of the transform-domain kernels
         if (!k->fn_img) return fail(h, RRV_E_ARG, "conv: this layer has no per-image-state kernel");
         fn = k->fn_img;
     }
