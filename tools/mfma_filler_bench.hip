@@ -85,7 +85,6 @@ __global__ __launch_bounds__(512, 1) void k2(float* out, int iters) {
         if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(v[j & 7]) : "v"(c));
         if (KIND == 3) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[j & 7][0]) : "v"(a));
         if (KIND == 9) asm volatile("s_mul_i32 %0, %0, %1" : "+s"(sc[j & 3]) : "s"(sk));                 // scalar ALU, four independent chains
-        if (KIND == 10) asm volatile("s_add_u32 %0, %0, %1\n\ts_addc_u32 %2, %2, 0" : "+s"(sc[0]), "+s"(sk), "+s"(sc[1]));   // 64-bit add: a dependent pair (counts as 2)
         if (KIND == 11) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sc[j & 3]) : "v"(a));            // what a spilled SGPR costs
     };
     __syncthreads();
@@ -141,7 +140,6 @@ int main() {
     // scalar work in the shadow of the MFMAs (item bookkeeping): how many SALU instructions per MFMA are free?
     run2<9, 1, 0, 0>("s_mul_i32", out); run2<9, 2, 0, 0>("s_mul_i32", out); run2<9, 4, 0, 0>("s_mul_i32", out); run2<9, 8, 0, 0>("s_mul_i32", out);
     run2<9, 12, 0, 0>("s_mul_i32", out); run2<9, 8, 1, 0>("s_mul_i32", out);
-    run2<10, 1, 0, 0>("s_add_u32 + s_addc_u32", out); run2<10, 2, 0, 0>("s_add_u32 + s_addc_u32", out); run2<10, 4, 0, 0>("s_add_u32 + s_addc_u32", out);
     run2<11, 1, 0, 0>("v_readlane_b32", out); run2<11, 2, 0, 0>("v_readlane_b32", out); run2<11, 4, 0, 0>("v_readlane_b32", out); run2<11, 4, 1, 0>("v_readlane_b32", out);
     run<0, 0>("bare MFMA stream", out);
     run<7, 1>("s_nop 0", out); run<7, 4>("s_nop 0", out);
