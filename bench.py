@@ -549,6 +549,13 @@ def main():
             for k in range(n1):
                 model.transfer(one[k])
             out["zero_copy_one_frame_per_call_frames_per_s"] = round(n1 / (time.perf_counter() - t1), 1)
+            for mode, key in ((2, "zero_copy_input_only_frames_per_s"), (3, "zero_copy_output_only_frames_per_s")):
+                model.set_host_io(mode)
+                model.transfer_batch(h_in[0], out=h_out[0])
+                t1 = time.perf_counter()
+                for i in range(nr2):
+                    model.transfer_batch(h_in[i % n_batches], out=h_out[i & 1])
+                out[key] = round(nr2 * B / (time.perf_counter() - t1), 1)
             model.set_host_io(0)
         if os.environ.get("RRV_BENCH_LAYERS"):
             out["layers"] = [{"layer": k, "ms_per_frame": round(v[1] / nprof / B, 4), "tflops": round(v[2] / v[1] / 1e9, 1),

@@ -207,7 +207,8 @@ int rrv_set_grid_share(rrv_handle h, int share);
 /* How the host-buffer entries (rrv_transfer, _batch, _frames, _async) cross PCIe.  0 (default): staged — H2D copy into
  * HBM, kernels, D2H copy, on dedicated copy streams.  1: zero copy — the first kernel reads the uint8 frames straight
  * from page-locked host memory and the last one stores the stylized frame there (caller buffers if they are
- * page-locked, the library's pinned staging otherwise): no copy kernels, no copy-stream events.  Same results bit for bit. */
+ * page-locked, the library's pinned staging otherwise): no copy kernels, no copy-stream events.  2 / 3: zero copy for the
+ * input / the output only, the other direction staged.  Same results bit for bit. */
 int rrv_set_host_io(rrv_handle h, int mode);
 
 /* Stream-ordered use of the *_device entries from a caller that produces / consumes the buffers on its own HIP

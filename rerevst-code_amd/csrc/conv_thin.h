@@ -220,10 +220,39 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
     }
     const f32x4 r = acc[0] + acc[1] + acc[2] + acc[3];
     // D: register i of lane 4*blk + j  =  pixel 4*blk + i of this wave, output channel j
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    const int jc = jb < 3 ? jb : 0;
+    const float bias = p.bias[jc], mj = mean[jc], sj = sd[jc];
+    const int blk = lane >> 2;
+    // Interior tiles (all 16 x 16 pixels delivered): the wave's 4 rows x 16 pixels x BGR go through LDS and leave as
+    // 48 lanes x 16 bytes = four contiguous 192-byte row pieces, instead of 4-byte stores 48 bytes apart — whole
+    // bursts for HBM and, when the output is mapped host memory (zero-copy, look-ahead tickets), for PCIe.
+    const int oy0 = p.out_H ? y0 - p.crop_top : y0, ox0 = p.out_H ? x0 - p.crop_left : x0;      // tile origin in the delivered image
+    const int OH = p.out_H ? p.out_H : p.H, OW = p.out_H ? p.out_W : p.W;
+    const bool whole = y0 + 16 <= p.H && x0 + 16 <= p.W && oy0 >= 0 && ox0 >= 0 && oy0 + 16 <= OH && ox0 + 16 <= OW;     // block-uniform
+    if (whole) {
+        // s_in[0] is free: the barrier at the top of the last chunk (which lives in s_in[1]) was passed by every wave
+        float* so = &s_in[0][0] + wave * 192;     // [4 rows][16 pixels][3]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = r[i] + bias;
+            if (p.out_pre && jb < 3) {
+                const int pix = 4 * blk + i;
+                p.out_pre[(((size_t)b * p.H + y0 + 4 * wave + (pix >> 4)) * p.W + x0 + (pix & 15)) * 3 + jb] = t;
+            }
+            float im = t * sj + mj;
+            im = fminf(fmaxf(im, 0.f), 1.f) * 255.f;
+            if (jb < 3) so[(4 * blk + i) * 3 + 2 - jb] = im;      // RGB -> BGR
+        }
+        // the wave's own 768 bytes: written and read by the same wave (LDS operations of a wave complete in order)
+        if (lane < 48) {
+            const int row = lane / 12, piece = lane - row * 12;
+            const f32x4 v = *(const f32x4*)(so + row * 48 + piece * 4);
+            *(f32x4*)(p.out_img + (((size_t)b * OH + oy0 + 4 * wave + row) * OW + ox0) * 3 + piece * 4) = v;
+        }
+        return;
+    }
     if (jb < 3) {
-        const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
-        const float bias = p.bias[jb], mj = mean[jb], sj = sd[jb];
-        const int blk = lane >> 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pix = 4 * blk + i;

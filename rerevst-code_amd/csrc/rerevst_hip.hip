@@ -160,7 +160,7 @@ struct rrv_ctx {
     long next_ticket = 0;
     int grid_share = 1;               // rrv_set_grid_share: persistent grids use 1/grid_share of the CUs
     int ms_group = 1;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
-    int host_io = 0;                  // rrv_set_host_io: 0 = staged H2D / D2H copies, 1 = zero copy (kernels read / write page-locked host memory)
+    int host_io = 0;                  // rrv_set_host_io: 0 = staged H2D / D2H copies, 1 = zero copy (kernels read / write page-locked host memory), 2 = input only, 3 = output only
     int n_cus = 256;
     int debug = 0;                    // rrv_set_debug / RRV_DEBUG: 1 = sync + check after every API call, 2 = after every kernel launch
     int fail_alloc_in = 0;            // rrv_debug_fail_alloc: the n-th next device allocation reports out-of-memory
@@ -1890,9 +1890,10 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
     RCHK(sync_all(h));
     const int nchunk = (B + sub - 1) / sub;
     const int nsets = nchunk < HOST_SETS ? nchunk : HOST_SETS;
+    const bool zin = h->host_io == 1 || h->host_io == 2, zout = h->host_io == 1 || h->host_io == 3;
     for (int i = 0; i < nsets; ++i) {
         auto& st = h->hstage[i];
-        if (h->host_io == 0 && st.cap < (size_t)sub * fb) {
+        if (h->host_io != 1 && st.cap < (size_t)sub * fb) {
             if (st.d_in) (void)hipFree(st.d_in);
             if (st.d_out) (void)hipFree(st.d_out);
             st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
@@ -1938,32 +1939,33 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
             h->next_slot = 0;
             return RRV_OK;
         }
-        if (h->host_io == 1) {       // zero copy: the first kernel reads the page-locked source over PCIe, the last one writes the destination
-            h->next_slot = slot;
-            float* dst = out_pin ? out + (size_t)k * sub * fo : st.pin_out;
-            if (reuse && out_pin) HIPCHK(hipStreamWaitEvent(cs, st.out_done, 0));      // (ordering only; a pinned destination is never re-used inside a call)
-            rc = pad_on_device ? rrv_transfer_frames_device(h, src, nb, H, W, dst) : rrv_transfer_batch_device(h, src, nb, H, W, dst);
-            if (rc != RRV_OK) break;
-            HIPCHK(hipEventRecord(st.out_done, cs));
-            continue;
+        // zero copy per direction (rrv_set_host_io: 1 both, 2 input only, 3 output only): the first kernel reads the page-locked
+        // source over PCIe / the last one writes the destination; the other direction keeps its copy stream
+        const uint8_t* k_in = src;
+        if (!zin) {
+            if (reuse) HIPCHK(hipStreamWaitEvent(h->copy_in, st.k_done, 0));       // the kernels of k-4 have read d_in
+            HIPCHK(hipMemcpyAsync(st.d_in, src, (size_t)nb * fb, hipMemcpyHostToDevice, h->copy_in));
+            HIPCHK(hipEventRecord(st.in_done, h->copy_in));
+            HIPCHK(hipStreamWaitEvent(cs, st.in_done, 0));
+            k_in = st.d_in;
         }
-        if (reuse) HIPCHK(hipStreamWaitEvent(h->copy_in, st.k_done, 0));       // the kernels of k-4 have read d_in
-        HIPCHK(hipMemcpyAsync(st.d_in, src, (size_t)nb * fb, hipMemcpyHostToDevice, h->copy_in));
-        HIPCHK(hipEventRecord(st.in_done, h->copy_in));
-        HIPCHK(hipStreamWaitEvent(cs, st.in_done, 0));
-        if (reuse) HIPCHK(hipStreamWaitEvent(cs, st.out_done, 0));             // d_out of k-4 has left the device
+        float* const h_dst = out_pin ? out + (size_t)k * sub * fo : st.pin_out;
+        if (reuse) HIPCHK(hipStreamWaitEvent(cs, st.out_done, 0));             // d_out / pin_out of k-4 has been delivered
         h->next_slot = slot;
-        rc = pad_on_device ? rrv_transfer_frames_device(h, st.d_in, nb, H, W, st.d_out) : rrv_transfer_batch_device(h, st.d_in, nb, H, W, st.d_out);
+        float* const k_out = zout ? h_dst : st.d_out;
+        rc = pad_on_device ? rrv_transfer_frames_device(h, k_in, nb, H, W, k_out) : rrv_transfer_batch_device(h, k_in, nb, H, W, k_out);
         if (rc != RRV_OK) break;
-        HIPCHK(hipEventRecord(st.k_done, cs));
+        if (!zin) HIPCHK(hipEventRecord(st.k_done, cs));
+        if (zout) { HIPCHK(hipEventRecord(st.out_done, cs)); continue; }
+        if (zin) HIPCHK(hipEventRecord(st.k_done, cs));
         HIPCHK(hipStreamWaitEvent(h->copy_out, st.k_done, 0));
-        HIPCHK(hipMemcpyAsync(out_pin ? (void*)(out + (size_t)k * sub * fo) : (void*)st.pin_out, st.d_out, (size_t)nb * fo * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
+        HIPCHK(hipMemcpyAsync(h_dst, st.d_out, (size_t)nb * fo * sizeof(float), hipMemcpyDeviceToHost, h->copy_out));
         HIPCHK(hipEventRecord(st.out_done, h->copy_out));
     }
     if (rc != RRV_OK) { (void)sync_all(h); h->next_slot = 0; return rc; }
     const int first_open = (!in_pin || !out_pin) ? (nchunk - HOST_SETS < 0 ? 0 : nchunk - HOST_SETS) : 0;
     if (in_pin && out_pin) {               // nothing to copy on the host: the last D2H of each stream order completes everything
-        if (h->host_io == 1) RCHK(sync_all(h));
+        if (zout) RCHK(sync_all(h));
         else HIPCHK(hipStreamSynchronize(h->copy_out));
     } else {
         for (int k = first_open; k < nchunk; ++k) RCHK(drain(k));
@@ -2022,6 +2024,14 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
             return fail(h, RRV_E_NOMEM, "transfer_async: out of page-locked host memory");
         st.pcap = fb;
     }
+    if (st.cap < fb) {        // device-side input of this set (d_out keeps host_pipeline's invariant: 4 x the input bytes)
+        if (st.d_in) (void)hipFree(st.d_in);
+        if (st.d_out) (void)hipFree(st.d_out);
+        st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
+        RCHK(dmalloc(h, (void**)&st.d_in, fb));
+        RCHK(dmalloc(h, (void**)&st.d_out, fb * sizeof(float)));
+        st.cap = fb;
+    }
     const uint8_t* src = frame;
     if (!in_pin) { memcpy(st.pin_in, frame, fb); src = st.pin_in; }
     // Four tickets may be open: each runs on its own (stream, workspace) with a quarter of the CUs per persistent grid, so
@@ -2038,12 +2048,15 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
         (void)hipGetLastError();
         h->grid_share = open > RRV_MAX_SLOTS ? RRV_MAX_SLOTS : open;
     }
-    // Zero copy, whatever rrv_set_host_io says: the first kernel reads `src` and the last one writes the destination in
-    // page-locked host memory.  (Staged copies would add two copy streams to the four compute streams — more streams than
-    // hardware queues, and a D2H copy then waits behind another frame's kernels: measured 230-260 frames/s against 551.)
+    // No copy streams, whatever rrv_set_host_io says: the frame is copied in on the ticket's OWN stream (1.2 MB; a
+    // kernel reading it from host memory byte by byte costs more, bench `zero_copy_input_only`) and the last kernel writes
+    // the destination in page-locked host memory in 192-byte bursts.  (Separate copy streams would add two streams to the
+    // four compute streams — more than hardware queues, and a D2H copy then waits behind another frame's kernels:
+    // measured 230-260 frames/s against 551.)
     RCHK(ensure_active(h));
+    HIPCHK(hipMemcpyAsync(st.d_in, src, fb, hipMemcpyHostToDevice, cs));
     h->next_slot = slot;
-    const int rc0 = transfer_device(h, src, 1, H, W, out_pin ? out : st.pin_out);
+    const int rc0 = transfer_device(h, st.d_in, 1, H, W, out_pin ? out : st.pin_out);
     h->next_slot = 0;
     if (rc0 != RRV_OK) return rc0;
     HIPCHK(hipEventRecord(st.out_done, cs));
@@ -2340,7 +2353,7 @@ int rrv_set_multistyle_group(rrv_handle h, int frames) {
 }
 
 int rrv_set_host_io(rrv_handle h, int mode) {
-    if (!h || mode < 0 || mode > 1) return RRV_E_ARG;
+    if (!h || mode < 0 || mode > 3) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     for (int i = 0; i < 4; ++i) RCHK(retire_ticket(h, i));
     RCHK(sync_all(h));

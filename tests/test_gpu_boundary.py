@@ -327,6 +327,12 @@ def test_async_tickets_equal_plain_transfer(hip, pkg, oracle):
         np.testing.assert_array_equal(batch[k], ref[2 + k])
     odd = pkg.synth_frame(940, 67, 93, kind="noise")               # 8*(H/8) x 8*(W/8) output
     np.testing.assert_array_equal(hip.result(hip.transfer_async(odd)), hip.transfer(odd))
+    t = hip.transfer_async(frames[0])
+    np.testing.assert_array_equal(hip.result(t), ref[0])
+    np.testing.assert_array_equal(hip.result(t), ref[0])           # waiting twice is harmless
+    with pytest.raises(pkg.RRVError) as e:                         # a ticket that was never issued
+        hip.result((t[0] + 1000, t[1]))
+    assert e.value.code == -1
 
 
 def test_feature_cache_cap_falls_back_to_reencoding(pkg, weights, oracle):
@@ -416,6 +422,14 @@ def test_zero_copy_host_io_equals_staged(hip, pkg, oracle):
             np.testing.assert_array_equal(hip.result(tickets[k]), ref[k])
         t = hip.transfer_async(pin_in[9], out=pin_out[0])
         np.testing.assert_array_equal(hip.result(t), ref[9])
+        for mode in (2, 3):                                                              # one direction zero copy, the other staged
+            hip.set_host_io(mode)
+            np.testing.assert_array_equal(hip.transfer_batch(frames), ref)
+            pin_out[...] = -1.0
+            hip.transfer_batch(pin_in, out=pin_out)
+            np.testing.assert_array_equal(pin_out, ref)
+            np.testing.assert_array_equal(hip.transfer_frames(raw), ref_raw)
+            np.testing.assert_array_equal(hip.transfer(frames[7]), ref[7])
     finally:
         hip.set_host_io(0)
     np.testing.assert_array_equal(hip.transfer_batch(frames), ref)
