@@ -2266,7 +2266,9 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
         h->cur = &h->sets[4 * slot];
         h->active_src = -2;
         h->next_slot = slot;
-        if (fp[0]) {
+        if (fp[0] && cnt == 1) {       // one frame per launch: its state set is simply the current one (shared-state kernels)
+            RCHK(transfer_device(h, nullptr, 1, H, W, st.d_out, fp[0]));
+        } else if (fp[0]) {
             h->state_images = cnt;
             const int rc = transfer_device(h, nullptr, cnt, H, W, st.d_out, nullptr, nullptr, fp);
             h->state_images = 0;
