@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
 struct LastP {
     const float* in;      // [B,H,W,64] ring layout
     int H, W, B;
-    const float* w;       // [9][64][4]: tap, cin, cout(rgb, padded to 4)
+    const float* w;       // pack_last_k: [blk 2][c 4][lane 64][s 4] MFMA A operands of the 27 x 64 tap-rgb matrix
     const float* bias;    // [4]
     float* out_img;       // [B][H][W][3] BGR float32 0..255
     float* out_pre;       // optional [B][H][W][3] RGB pre-clamp (normalised units), may be null
@@ -163,114 +163,96 @@ struct LastP {
     int ty0, tx0;         // first tile row / column of the computed window (tiles_x, tiles_y count its tiles)
 };
 
-// Matrix-core form: v_mfma_f32_4x4x1_16B_f32 runs 16 independent 4x4 outer products per instruction
-// (lane 4b+i feeds A-row i of block b, lane 4b+j feeds B-column j; D[i][j] of block b = register i of lane
-// 4b+j), so a wave evaluates 64 pixels x 4 output channels per K step with no padding to 16/32 channels:
-// A = the pixel's input value (one lane per pixel), B = w[k][rgb] replicated over the blocks.
-// LDS: 18x18x16-channel halo chunks (double-buffered LDS-DMA) + the whole weight table [tap][chunk][4][16].
+// GEMM first, taps second.  out[y][x][rgb] = sum_tap sum_c w[tap][c][rgb] in[y+ky][x+kx][c] is evaluated as
+//   G[p][tap*3+rgb] = sum_c W[tap*3+rgb][c] in[p][c]     for the 18 x 18 halo pixels p of a 16 x 16 tile — one
+//                     [27 -> 32] x [64] x [324] GEMM on v_mfma_f32_16x16x4_f32, the input straight from global memory
+//                     into the B operand (each value is read ONCE), the weights resident in 32 registers per lane,
+//   out[y][x][rgb] = bias + sum_tap G[(y+ky, x+kx)][tap*3+rgb]      27 shifted LDS reads per output value (planes of
+//                     324 floats: consecutive lanes = consecutive pixels, conflict-free).
+// Round 2's direct form re-read every input value from LDS for each of its nine taps (288 ds_read_b128 per wave and
+// tile, LDS-bound at 0.38 of the HBM peak); here LDS carries 27 floats per halo pixel once in and once out.
+// Workgroups are persistent (the weight registers are loaded once) and walk the tiles of the window.
+#define LAST_GP 330       /* floats per G plane (324 used); 4 planes = 8 banks on: the four row groups of a wave write disjoint banks */
 __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
-    __shared__ __attribute__((aligned(16))) float s_in[2][18 * 18 * 16];
-    __shared__ __attribute__((aligned(16))) float s_w[9 * 4 * 4 * 16];
+    __shared__ __attribute__((aligned(16))) float s_g[27 * LAST_GP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int bx = blockIdx.x;
-    const int tx = bx % p.tiles_x;
-    bx /= p.tiles_x;
-    const int ty = bx % p.tiles_y, b = bx / p.tiles_y;
-    const int y0 = (ty + p.ty0) * 16, x0 = (tx + p.tx0) * 16;
-    // 64-bit tile origin, tile-relative 32-bit lane offsets: no limit on the frame size from the descriptor's range
-    const float* in_t = p.in + ((size_t)b * (size_t)(p.H + 2) + y0) * (size_t)(p.W + 2) * 64 + (size_t)x0 * 64;
-
-    auto stage = [&](int chunk, int buf) {
-        for (int e = tid; e < 18 * 18 * 4; e += 256) {
-            const int pp = e >> 2, qq = e & 3;
-            const int hy = pp / 18, hx = pp - hy * 18;
-            const int off = ((hy * (p.W + 2) + hx) * 64 + 4 * (qq ^ ((pp >> 2) & 3))) * 4;
-            bufld16(in_t, (char*)&s_in[buf][0] + (e - (tid & 63)) * 16, off, chunk * 64);
-        }
-    };
-    stage(0, 0);
-    // weights: p.w is [9][64][4] (tap, cin, rgb-padded); LDS image [tap][chunk][j][16 cin]
-    for (int i = tid; i < 9 * 64 * 4; i += 256) {
-        const int j = i & 3, ci = (i >> 2) & 63, tap = i >> 8;
-        s_w[((tap * 4 + (ci >> 4)) * 4 + j) * 16 + (ci & 15)] = p.w[i];
-    }
-    const int prow = lane >> 4, pcol = lane & 15;   // this lane's pixel as the A operand: wave rows 4w..4w+3
-    const int jb = lane & 3;                        // this lane's output channel as the B operand / D column
-    f32x4 acc[4];
+    const int t = lane & 15, kq = lane >> 4;
+    f32x4 wreg[2][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int chunk = 0; chunk < 4; ++chunk) {
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wreg[blk][c] = *(const f32x4*)(p.w + ((blk * 4 + c) * 64 + lane) * 4);
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    const float bias[3] = {p.bias[0], p.bias[1], p.bias[2]};
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const int OH = p.out_H ? p.out_H : p.H, OW = p.out_H ? p.out_W : p.W;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+        const int y0 = (ty + p.ty0) * 16, x0 = (tx + p.tx0) * 16;
+        // 64-bit tile origin (halo pixel (0,0) = ring pixel (y0, x0)), tile-relative 32-bit lane offsets
+        const float* in_t = p.in + ((size_t)b * (size_t)(p.H + 2) + y0) * (size_t)(p.W + 2) * 64 + (size_t)x0 * 64 + 4 * kq;
+        // ---- G = W . in over the halo: 21 groups of 16 pixels, round-robin over the waves
+        auto halo_off = [&](int g) {
+            int P = 16 * g + t;
+            P = P < 324 ? P : 323;
+            const int hy = P / 18, hx = P - 18 * hy;
+            return (hy * (p.W + 2) + hx) * 64;
+        };
+        f32x4 x[4], xn[4];
+        {
+            const float* src = in_t + halo_off(wave);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = *(const f32x4*)(src + 16 * c);
+        }
+        for (int g = wave; g < 21; g += 4) {
+            if (g + 4 < 21) {                 // next group's pixels while this one is multiplied
+                const float* src = in_t + halo_off(g + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xn[c] = *(const f32x4*)(src + 16 * c);
+            }
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[blk][c][s], x[c][s], acc[blk], 0, 0, 0);
+            // D: register i of lane (pixel t, row group kq) = row n = 16 blk + 4 kq + i of that pixel
+            const int P = 16 * g + t;
+            if (P < 324) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n = 16 * blk + 4 * kq + i;
+                        if (n < 27) s_g[n * LAST_GP + P] = acc[blk][i];
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = xn[c];
+        }
         __syncthreads();
-        if (chunk + 1 < 4) stage(chunk + 1, (chunk + 1) & 1);
-        const char* buf = (const char*)&s_in[chunk & 1][0];
+        // ---- taps: one output pixel per lane (wave w = tile rows 4w .. 4w+3)
+        const int row = 4 * wave + (lane >> 4), col = lane & 15;
+        float o[3] = {bias[0], bias[1], bias[2]};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int pp = (4 * wave + prow + ky) * 18 + pcol + kx;
-            const int sw = (pp >> 2) & 3;
-            const float* wt = &s_w[((tap * 4 + chunk) * 4 + jb) * 16];
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const float* gp = &s_g[(tap * 3) * LAST_GP + (row + ky) * 18 + col + kx];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = *(const f32x4*)(buf + pp * 64 + ((q ^ sw) << 4));
-                const f32x4 w4 = *(const f32x4*)(wt + q * 4);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s], w4[s], acc[q], 0, 0, 0);
-            }
+            for (int c = 0; c < 3; ++c) o[c] += gp[c * LAST_GP];
         }
-    }
-    const f32x4 r = acc[0] + acc[1] + acc[2] + acc[3];
-    // D: register i of lane 4*blk + j  =  pixel 4*blk + i of this wave, output channel j
-    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
-    const int jc = jb < 3 ? jb : 0;
-    const float bias = p.bias[jc], mj = mean[jc], sj = sd[jc];
-    const int blk = lane >> 2;
-    // Interior tiles (all 16 x 16 pixels delivered): the wave's 4 rows x 16 pixels x BGR go through LDS and leave as
-    // 48 lanes x 16 bytes = four contiguous 192-byte row pieces, instead of 4-byte stores 48 bytes apart — whole
-    // bursts for HBM and, when the output is mapped host memory (zero-copy, look-ahead tickets), for PCIe.
-    const int oy0 = p.out_H ? y0 - p.crop_top : y0, ox0 = p.out_H ? x0 - p.crop_left : x0;      // tile origin in the delivered image
-    const int OH = p.out_H ? p.out_H : p.H, OW = p.out_H ? p.out_W : p.W;
-    const bool whole = y0 + 16 <= p.H && x0 + 16 <= p.W && oy0 >= 0 && ox0 >= 0 && oy0 + 16 <= OH && ox0 + 16 <= OW;     // block-uniform
-    if (whole) {
-        // s_in[0] is free: the barrier at the top of the last chunk (which lives in s_in[1]) was passed by every wave
-        float* so = &s_in[0][0] + wave * 192;     // [4 rows][16 pixels][3]
+        __syncthreads();                      // G is free for the next tile
+        const int y = y0 + row, xx = x0 + col;
+        if (y < p.H && xx < p.W) {
+            typedef float f32x3 __attribute__((ext_vector_type(3)));
+            if (p.out_pre) *(f32x3*)(p.out_pre + (((size_t)b * p.H + y) * p.W + xx) * 3) = f32x3{o[0], o[1], o[2]};
+            float im[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float t = r[i] + bias;
-            if (p.out_pre && jb < 3) {
-                const int pix = 4 * blk + i;
-                p.out_pre[(((size_t)b * p.H + y0 + 4 * wave + (pix >> 4)) * p.W + x0 + (pix & 15)) * 3 + jb] = t;
-            }
-            float im = t * sj + mj;
-            im = fminf(fmaxf(im, 0.f), 1.f) * 255.f;
-            if (jb < 3) so[(4 * blk + i) * 3 + 2 - jb] = im;      // RGB -> BGR
-        }
-        // the wave's own 768 bytes: written and read by the same wave (LDS operations of a wave complete in order)
-        if (lane < 48) {
-            const int row = lane / 12, piece = lane - row * 12;
-            const f32x4 v = *(const f32x4*)(so + row * 48 + piece * 4);
-            *(f32x4*)(p.out_img + (((size_t)b * OH + oy0 + 4 * wave + row) * OW + ox0) * 3 + piece * 4) = v;
-        }
-        return;
-    }
-    if (jb < 3) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pix = 4 * blk + i;
-            const int y = y0 + 4 * wave + (pix >> 4), x = x0 + (pix & 15);
-            if (y < p.H && x < p.W) {
-                const size_t o = (((size_t)b * p.H + y) * p.W + x) * 3;
-                const float t = r[i] + bias;
-                if (p.out_pre) p.out_pre[o + jb] = t;
-                float im = t * sj + mj;
-                im = fminf(fmaxf(im, 0.f), 1.f) * 255.f;
-                if (!p.out_H) {
-                    p.out_img[o + 2 - jb] = im;   // RGB -> BGR
-                } else {
-                    const int cy = y - p.crop_top, cx = x - p.crop_left;
-                    if (cy >= 0 && cy < p.out_H && cx >= 0 && cx < p.out_W)
-                        p.out_img[(((size_t)b * p.out_H + cy) * p.out_W + cx) * 3 + 2 - jb] = im;
-                }
-            }
+            for (int c = 0; c < 3; ++c) im[c] = fminf(fmaxf(o[c] * sd[c] + mean[c], 0.f), 1.f) * 255.f;
+            const int cy = p.out_H ? y - p.crop_top : y, cx = p.out_H ? xx - p.crop_left : xx;
+            // RGB -> BGR; a lane stores its pixel's 12 bytes, a row of the tile leaves as one 192-byte burst
+            if (cy >= 0 && cy < OH && cx >= 0 && cx < OW) *(f32x3*)(p.out_img + (((size_t)b * OH + cy) * OW + cx) * 3) = f32x3{im[2], im[1], im[0]};
         }
     }
 }

@@ -61,12 +61,15 @@ __global__ void pack_first_grey_k(const float* __restrict__ w, const float* __re
     }
 }
 
-// conv_last weights: OIHW [3][64][3][3] -> [9][64][4]
+// conv_last weights: OIHW [3][64][3][3] -> the A-operand registers of conv_last_k: [blk 2][c 4][lane 64][s 4], the value
+// lane (m = lane & 15, kq = lane >> 4) feeds to the MFMA of channel chunk c, step s, row block blk:
+// W[n = 16 blk + m][channel 16 c + 4 kq + s] with n = tap * 3 + rgb (27 rows, padded to 32 with zeros)
 __global__ void pack_last_k(const float* __restrict__ w, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 9 * 64 * 4) {
-        const int co = i & 3, ci = (i >> 2) & 63, tap = i >> 8;
-        dst[i] = (co < 3) ? w[(co * 64 + ci) * 9 + tap] : 0.f;
+    if (i < 2 * 4 * 64 * 4) {
+        const int s = i & 3, lane = (i >> 2) & 63, c = (i >> 8) & 3, blk = i >> 10;
+        const int n = 16 * blk + (lane & 15), ch = 16 * c + 4 * (lane >> 4) + s;
+        dst[i] = (n < 27) ? w[((n % 3) * 64 + ch) * 9 + n / 3] : 0.f;
     }
 }
 

@@ -829,7 +829,8 @@ int run_last(rrv_handle h, const Tens& o2, int B, int H, int W, float* d_out, fl
     if (wl) { lp.ty0 = wl->y0 / 16; lp.tx0 = wl->x0 / 16; lp.tiles_y = (wl->y1 - wl->y0) / 16; lp.tiles_x = (wl->x1 - wl->x0) / 16; }
     h->last_pre = pre; h->last_pre_H = H; h->last_pre_W = W;
     return launch(h, "conv_last", 2.0 * B * H * W * 576 * 3, (256.0 + 12.0) * B * H * W, [&] {
-        hipLaunchKernelGGL(conv_last_k, dim3(lp.tiles_x * lp.tiles_y * B), dim3(256), 0, h->stream, lp);
+        const unsigned tiles = (unsigned)(lp.tiles_x * lp.tiles_y * B), resident = (unsigned)h->n_cus * 4;     // persistent: 4 workgroups of 35 KB per CU
+        hipLaunchKernelGGL(conv_last_k, dim3(tiles < resident ? tiles : resident), dim3(256), 0, h->stream, lp);
     });
 }
 
@@ -1474,8 +1475,8 @@ int rrv_finalize_weights(rrv_handle h) {
     {
         float* raw = nullptr;
         RCHK(upload(h, "Decoder.slice1.weight", &raw, 3 * 64 * 9));
-        RCHK(dalloc(h, &h->last_w, 9 * 64 * 4, false));
-        hipLaunchKernelGGL(pack_last_k, dim3(9), dim3(256), 0, h->stream, (const float*)raw, h->last_w);
+        RCHK(dalloc(h, &h->last_w, 2 * 4 * 64 * 4, false));
+        hipLaunchKernelGGL(pack_last_k, dim3(8), dim3(256), 0, h->stream, (const float*)raw, h->last_w);
         HIPCHK(hipGetLastError());
         RCHK(dalloc(h, &h->last_b, 4, true));
         auto it = h->hostw.find("Decoder.slice1.bias");
