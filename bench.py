@@ -55,7 +55,7 @@ def rocprof_name(kernel):
     if base == "conv_wino":      # the row-split 8-wave kernel, <EPI, ABL>
         return "void conv_wino_split_k<%s, 0>(ConvP)" % epi(args)
     if base in ("conv_upw", "conv_upw_sc"):       # conv_wino_k<EPI, ABL, waves, UPS, SC>: rerevst_hip.hip UPW_NW
-        return "void conv_wino_k<%s, 0, 4, 1, %d>(ConvP)" % (epi(args), 1 if base.endswith("_sc") else 0)
+        return "void conv_wino_k<%s, 0, 4, 1, %d, 0>(ConvP)" % (epi(args), 1 if base.endswith("_sc") else 0)      # last: PERIMG
     if base == "conv_mfma":
         bn, taps, e = args.split(",", 2)
         return "void conv_mfma_k<%s, %s, %s, 0, 0, 1>(ConvP)" % (bn.strip(), taps.strip(), epi(e))
@@ -75,9 +75,12 @@ def measured_traffic(kernel, size=512, multistyle=0):
         with open(traffic_file(size, multistyle)) as f:
             t = json.load(f)
         name = rocprof_name(kernel)
-        for k, v in t["kernels"].items():
-            if k == name or k.startswith(name + "("):
-                return v["bytes_per_launch"]
+        # the per-image-state instantiation (last template argument 1) is the same kernel for this purpose: config 5's
+        # grouped launches run it, everything else the shared-state one
+        for cand in (name, name.replace(", 0>(ConvP)", ", 1>(ConvP)")):
+            for k, v in t["kernels"].items():
+                if k == cand or k.startswith(cand + "("):
+                    return v["bytes_per_launch"]
         return None
     except Exception:
         return None
