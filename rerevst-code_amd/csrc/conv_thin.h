@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
             f32x4 r;
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e], 0.f);
-            *(f32x4*)&orow[pc * 64] = r;
+            __builtin_nontemporal_store(r, (f32x4*)&orow[pc * 64]);
         }
         return;
     }
