@@ -219,6 +219,81 @@ def run_multistyle(name, weights, S=2, wts=(0.3, 0.7)):
              pre_crop=pre[64:128, 64:112].astype(np.float32), out_crop=out[64:128, 64:112].astype(np.float32))
 
 
+def run_real_multistyle(name, weights):
+    """The multi-style flow of "Multi-style Interpolation/test.py" on real images: two styles from the reference's data/
+    (img_1.jpg, img_5.jpg, resized to 384 x 384 as test.py:53 does), the 33 ambush_4 frames padded to 576 x 1152 and
+    encoded once (test.py:87-101), every 16th cached feature + the last one for the statistics (:103-110), frame 7
+    decoded with the script's ramp weights [i/(n-1), 1-i/(n-1)] (:127-131).  Stored: the resized styles and the frames
+    used (PNG), both state blobs, stride-4 grid + channel means + one dense patch of the pre-clamp / final crop."""
+    import glob
+    sty_mod, net_mod = R.import_reference("Multi-style Interpolation", "stylization", "style_network")
+    V = importlib.import_module("rerevst-code_amd.video")
+    S = 2
+    s = sty_mod.Stylization.__new__(sty_mod.Stylization)
+    s.device = torch.device("cpu")
+    s.transformer = net_mod.TransformerNet(style_num=S)
+    new = {}
+    for k, v in s.transformer.state_dict().items():
+        new[k] = torch.from_numpy(weights[k].copy()) if k in weights else torch.zeros_like(v)
+    s.transformer.load_state_dict(new, strict=True)
+    styles = [V.resize_bilinear(_imread_bgr(R.REF_ROOT + "/data/img_%d.jpg" % k), (384, 384)) for k in (1, 5)]
+    paths = sorted(glob.glob(R.REF_ROOT + "/test/inputs/ambush_4/*.png"))
+    n = len(paths)
+    ids = V.sample_indices_multistyle(n, 16)
+    tid = 7
+    wts = [float(v) for v in V.ramp_weights(tid, n, S)]
+    used = sorted(set(ids + [tid]))
+    frames = {i: _imread_bgr(paths[i]) for i in used}
+    padded = {i: O.reflect_pad(frames[i], 576, 1152) for i in used}
+    s.prepare_style(styles)
+    feats = {i: s.generate_content_features(padded[i].copy()) for i in used}
+    s.clean()
+    for i in ids:
+        s.add_patch(feats[i])
+    s.compute_norm()
+    out = s.transfer(feats[tid], wts)[64:500, 64:1088]
+    with torch.no_grad():
+        pre = nhwc(s.transformer(feats[tid], wts))[0][64:500, 64:1088]
+    d = s.transformer.Decoder
+    norms = list(d.norm) + [d.slice4.norm1, d.slice4.norm2, d.slice3.norm1, d.slice3.norm2, d.slice2.norm1, d.slice2.norm2]
+    blobs = []
+    for sid in range(S):
+        parts = []
+        for nn_ in norms:
+            for t in (nn_.saved_mean[sid], nn_.saved_std[sid], nn_.x_min[sid], nn_.x_max[sid]):
+                parts.append(t.reshape(-1).numpy())
+        for f in (d.Filter1, d.Filter2, d.Filter3):
+            for g in (f.F1, f.F2):
+                parts.append(g.filter[sid].reshape(-1).numpy())
+        for k, nm in enumerate(O.STYLE_NAMES):
+            ms = getattr(s.transformer.F_style[sid], nm)
+            parts += [ms.mean.reshape(-1).numpy(), ms.std.reshape(-1).numpy()]
+        blobs.append(np.concatenate(parts).astype(np.float32))
+    O.set_conv_backend("torch")
+    o = O.MultiStylization(weights, S)
+    o.prepare_style(styles)
+    of = {i: o.generate_content_features(padded[i]) for i in used}
+    o.clean()
+    for i in ids:
+        o.add_patch(of[i])
+    o.compute_norm()
+    opre = o.transfer(of[tid], wts, return_preclamp=True)[0][64:500, 64:1088]
+    O.set_conv_backend("numpy")
+    print("[%s] ids %s tid %d wts %s | state rel err max %s | pre-clamp max|d| %.3e (std %.3f) | sat frac %.3f"
+          % (name, ids, tid, wts, " / ".join("%.3e" % float((np.abs(o.get_state(i) - blobs[i]) / (np.abs(blobs[i]) + 1e-3)).max()) for i in range(S)),
+             np.abs(opre - pre).max(), pre.std(), float(np.mean((out <= 0) | (out >= 255)))))
+    g = {"state%d" % i: blobs[i] for i in range(S)}
+    g.update(weights=np.array(wts, np.float32), sample_ids=np.array(ids), transfer_id=np.array(tid),
+             pre_grid=pre[::4, ::4].astype(np.float32), out_grid=out[::4, ::4].astype(np.float32),
+             pre_patch=pre[186:250, 480:544].astype(np.float32), out_patch=out[186:250, 480:544].astype(np.float32),
+             pre_chanmean=pre.mean(axis=(0, 1)).astype(np.float32), out_chanmean=out.mean(axis=(0, 1)).astype(np.float32))
+    for k in range(S):
+        g["style%d_png" % k] = _png(styles[k])
+    for i in used:
+        g["frame%d_png" % i] = _png(frames[i])
+    np.savez(os.path.join(HERE, name + ".npz"), **g)
+
+
 def run_frame_mode(name, weights):
     """use_Global=False (test/style_network_frame.py): per-frame statistics, no saved state."""
     fw, G = R.import_reference("test", "framework", "style_network_frame")
@@ -383,6 +458,8 @@ def main():
                 run_real_default(name, pkg.synthetic_weights(0))
             elif name == "img1_256":
                 run_img1_256(name, pkg.synthetic_weights(0))
+            elif name == "real_multistyle":
+                run_real_multistyle(name, pkg.synthetic_weights(0))
             elif name.startswith("global_a_"):
                 run_case(name, pkg.weight_variant(name[len("global_a_"):]), (64, 64), (64, 48), 4, [0, 1, 3], 2, crop_only=False,
                          fp64=name.endswith("dec4"))
@@ -401,6 +478,7 @@ def main():
     # round 3: the reference's own inputs, a second weight draw, wider / degenerate dynamic ranges
     run_real_default("real_default", w)
     run_img1_256("img1_256", w)
+    run_real_multistyle("real_multistyle", w)
     for v in ("seed1", "dec4", "dead"):
         run_case("global_a_" + v, pkg.weight_variant(v), (64, 64), (64, 48), 4, [0, 1, 3], 2, crop_only=False, fp64=(v == "dec4"))
 

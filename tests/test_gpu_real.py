@@ -88,3 +88,37 @@ def test_ill_conditioned_weights_dec4(pkg, oracle):
     assert_pre_close(s.preclamp(192, 192), g["pre"])
     assert np.abs(out - g["out"]).max() <= IMG_ATOL
     s.close()
+
+
+def test_real_multistyle_matches_reference(pkg, weights, oracle):
+    """The multi-style flow on real images (tests/golden/real_multistyle: data/img_1.jpg + img_5.jpg at 384 x 384, ambush_4
+    padded to 576 x 1152, statistics from features 0, 16, 32, 32, frame 7 with the script's ramp weights): the feature
+    API, the blended full-frame entry and the batched decoder entry against the unmodified reference."""
+    g = load_golden("real_multistyle")
+    styles = [decode_png(g["style%d_png" % k]) for k in range(2)]
+    ids, tid = [int(i) for i in g["sample_ids"]], int(g["transfer_id"])
+    wts = [float(v) for v in g["weights"]]
+    s = pkg.MultiStyleStylization(weights, cuda=True, style_num=2)
+    s.prepare_style(styles)
+    padded = {i: oracle.reflect_pad(decode_png(g["frame%d_png" % i]), 576, 1152) for i in sorted(set(ids + [tid]))}
+    feats = {i: s.generate_content_features(padded[i]) for i in padded}
+    s.clean()
+    for i in ids:
+        s.add_patch(feats[i])
+    s.compute_norm()
+    for k in range(2):
+        assert_state_close(s.get_state(k), g["state%d" % k], "style %d" % k)
+    out = s.transfer(feats[tid], wts)[64:500, 64:1088]
+    pre = s.preclamp(576, 1152)[64:500, 64:1088]
+    assert_pre_close(pre[::4, ::4], g["pre_grid"])
+    assert_pre_close(pre[186:250, 480:544], g["pre_patch"])
+    np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=2e-5)
+    assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
+    assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
+    np.testing.assert_allclose(out.mean(axis=(0, 1)), g["out_chanmean"], atol=2e-3)
+    many = s.transfer_many([feats[tid], feats[0]], [wts, [0.0, 1.0]])                 # the driver's frame loop in one call
+    np.testing.assert_array_equal(many[0][64:500, 64:1088], out)
+    full = pkg.Stylization.transfer(s, padded[tid], style_weight=wts)[64:500, 64:1088]      # encoder + blended decoder from the frame
+    assert np.abs(full - out).max() <= 1e-3
+    s.release_features()
+    s.close()

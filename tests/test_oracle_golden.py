@@ -221,3 +221,34 @@ def test_real_default_matches_reference(oracle, pkg, weights):
     np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=2e-5)
     assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
     assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
+
+
+def test_real_multistyle_matches_reference(oracle, pkg, weights):
+    """"Multi-style Interpolation/test.py" on real images: two styles from the reference's data/ at 384x384, the ambush_4
+    frames padded to 576x1152, features 0, 16, 32 + the last again for the statistics, frame 7 with the script's ramp."""
+    g = load_golden("real_multistyle")
+    styles = [decode_png(g["style%d_png" % k]) for k in range(2)]
+    ids, tid = [int(i) for i in g["sample_ids"]], int(g["transfer_id"])
+    assert styles[0].shape == (384, 384, 3) and ids == oracle.sample_indices_multistyle(33) == [0, 16, 32, 32]
+    wts = [float(v) for v in g["weights"]]
+    np.testing.assert_allclose(wts, [tid / 32.0, 1 - tid / 32.0], atol=1e-7)        # test.py:127-131
+    oracle.set_conv_backend("torch")
+    try:
+        o = oracle.MultiStylization(weights, 2)
+        o.prepare_style(styles)
+        feats = {i: o.generate_content_features(oracle.reflect_pad(decode_png(g["frame%d_png" % i]), 576, 1152)) for i in sorted(set(ids + [tid]))}
+        o.clean()
+        for i in ids:
+            o.add_patch(feats[i])
+        o.compute_norm()
+        for k in range(2):
+            assert_state_close(o.get_state(k), g["state%d" % k], "style %d" % k)
+        pre = o.transfer(feats[tid], wts, return_preclamp=True)[0][64:500, 64:1088]
+        out = o.transfer(feats[tid], wts)[64:500, 64:1088]
+    finally:
+        oracle.set_conv_backend("numpy")
+    assert_pre_close(pre[::4, ::4], g["pre_grid"])
+    assert_pre_close(pre[186:250, 480:544], g["pre_patch"])
+    np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=2e-5)
+    assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
+    assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL

@@ -68,3 +68,18 @@ for v in ("seed1", "dead", "dec4"):
     out = hip.transfer(O.reflect_pad(frames[tid], 192, 192)); pre = hip.preclamp(192, 192)
     report("global_a_" + v, st, g["state"], pre, g["pre"], out, g["out"], extra)
     hip.close()
+# round 3: the multi-style flow on real images
+g = T.load_golden("real_multistyle")
+ms = pkg.MultiStyleStylization(pkg.synthetic_weights(0), cuda=True, style_num=2)
+ms.prepare_style([T.decode_png(g["style%d_png" % k]) for k in range(2)])
+ids, tid = [int(i) for i in g["sample_ids"]], int(g["transfer_id"])
+feats = {i: ms.generate_content_features(O.reflect_pad(T.decode_png(g["frame%d_png" % i]), 576, 1152)) for i in sorted(set(ids + [tid]))}
+ms.clean()
+for i in ids: ms.add_patch(feats[i])
+ms.compute_norm()
+out = ms.transfer(feats[tid], [float(v) for v in g["weights"]])[64:500, 64:1088]
+pre = ms.preclamp(576, 1152)[64:500, 64:1088]
+w1, where1 = T.state_worst(ms.get_state(1), g["state1"])
+report("real_multistyle (img_1 + img_5 at 384x384, ambush_4, weights %.3f/%.3f; state of style 0 below, style 1 at %.0f%%)" % (g["weights"][0], g["weights"][1], 100 * w1),
+       ms.get_state(0), g["state0"], pre[::4, ::4], g["pre_grid"], out[::4, ::4], g["out_grid"])
+ms.close()
