@@ -322,6 +322,39 @@ def run_frame_mode(name, weights):
              out_crop=out[64:128, 64:112].astype(np.float32))
 
 
+def run_real_frame_mode(name, weights):
+    """use_Global=False on the reference's default inputs (generate_real_video.py:35 switches the network class): style
+    plum_flower.jpg 400x564, ambush_4 frame 12 padded to 576x1152.  The inputs are the ones stored in real_default.npz;
+    this fixture holds outputs only."""
+    import glob
+    fw, G = R.import_reference("test", "framework", "style_network_frame")
+    s = fw.Stylization.__new__(fw.Stylization)
+    s.device = torch.device("cpu")
+    s.model = G.TransformerNet()
+    new = {}
+    for k, v in s.model.state_dict().items():
+        new[k] = torch.from_numpy(weights[k].copy()) if k in weights else torch.zeros_like(v)
+    s.model.load_state_dict(new, strict=True)
+    style = _imread_bgr(R.REF_ROOT + "/test/inputs/plum_flower.jpg")
+    frame = O.reflect_pad(_imread_bgr(sorted(glob.glob(R.REF_ROOT + "/test/inputs/ambush_4/*.png"))[12]), 576, 1152)
+    s.prepare_style(style)
+    taps = {}
+    hk = s.model.Decoder.slice1.register_forward_hook(lambda m, i, o: taps.__setitem__("pre", nhwc(o)))
+    out = s.transfer(frame.copy())[64:500, 64:1088]
+    hk.remove()
+    pre = taps["pre"][0][64:500, 64:1088]
+    O.set_conv_backend("torch")
+    o = O.Stylization(weights, use_Global=False)
+    o.prepare_style(style)
+    opre = o.transfer(frame, return_preclamp=True)[0][64:500, 64:1088]
+    O.set_conv_backend("numpy")
+    print("[%s] pre-clamp max|d| %.3e (std %.3f) | sat frac %.3f" % (name, np.abs(opre - pre).max(), pre.std(), float(np.mean((out <= 0) | (out >= 255)))))
+    np.savez(os.path.join(HERE, name + ".npz"), transfer_id=np.array(12),
+             pre_grid=pre[::4, ::4].astype(np.float32), out_grid=out[::4, ::4].astype(np.float32),
+             pre_patch=pre[186:250, 480:544].astype(np.float32), out_patch=out[186:250, 480:544].astype(np.float32),
+             pre_chanmean=pre.mean(axis=(0, 1)).astype(np.float32), out_chanmean=out.mean(axis=(0, 1)).astype(np.float32))
+
+
 def run_config2(name, weights):
     """BASELINE config 2 geometry: 100-frame 256x256 video (padded 384x384), 512x512 style, the driver's sampling
     schedule (13 sampled frames: two encoder groups in the HIP library's deferred add, B = 13 in compute()).
@@ -458,6 +491,8 @@ def main():
                 run_real_default(name, pkg.synthetic_weights(0))
             elif name == "img1_256":
                 run_img1_256(name, pkg.synthetic_weights(0))
+            elif name == "real_frame_mode":
+                run_real_frame_mode(name, pkg.synthetic_weights(0))
             elif name == "real_multistyle":
                 run_real_multistyle(name, pkg.synthetic_weights(0))
             elif name.startswith("global_a_"):
@@ -479,6 +514,7 @@ def main():
     run_real_default("real_default", w)
     run_img1_256("img1_256", w)
     run_real_multistyle("real_multistyle", w)
+    run_real_frame_mode("real_frame_mode", w)
     for v in ("seed1", "dec4", "dead"):
         run_case("global_a_" + v, pkg.weight_variant(v), (64, 64), (64, 48), 4, [0, 1, 3], 2, crop_only=False, fp64=(v == "dec4"))
 

@@ -2,7 +2,9 @@
 * real_default: test/generate_real_video.py's default invocation (plum_flower.jpg at its native 400x564 on the
   ambush_4 frames at 436x1024: neither size is a multiple of 8), frame 12 padded to 576x1152;
 * img1_256: BASELINE config 1 (data/img_1.jpg on one 256x256 natural frame, B = 1);
-* global_a with a second weight draw, with dead / constant channels, and with every decoder weight x 4.
+* global_a with a second weight draw, with dead / constant channels, and with every decoder weight x 4;
+* real_multistyle: "Multi-style Interpolation/test.py"'s flow on data/img_1.jpg + img_5.jpg and the ambush_4 frames;
+* real_frame_mode: use_Global=False on the default inputs.
 All through the C ABI against outputs of the unmodified reference (tests/golden/make_goldens.py)."""
 import numpy as np
 import pytest
@@ -121,4 +123,22 @@ def test_real_multistyle_matches_reference(pkg, weights, oracle):
     full = pkg.Stylization.transfer(s, padded[tid], style_weight=wts)[64:500, 64:1088]      # encoder + blended decoder from the frame
     assert np.abs(full - out).max() <= 1e-3
     s.release_features()
+    s.close()
+
+
+def test_real_frame_mode_matches_reference(pkg, weights, oracle):
+    """Stylization(use_Global=False) on the reference's default inputs (tests/golden/real_frame_mode; inputs from
+    real_default.npz): per-frame statistics at 576 x 1152 against the unmodified style_network_frame.py."""
+    g, gin = load_golden("real_frame_mode"), load_golden("real_default")
+    tid = int(g["transfer_id"])
+    s = pkg.Stylization(weights, cuda=True, use_Global=False)
+    s.prepare_style(decode_png(gin["style_png"]))
+    out = s.transfer(oracle.reflect_pad(decode_png(gin["frame%d_png" % tid]), 576, 1152))[64:500, 64:1088]
+    pre = s.preclamp(576, 1152)[64:500, 64:1088]
+    assert_pre_close(pre[::4, ::4], g["pre_grid"])
+    assert_pre_close(pre[186:250, 480:544], g["pre_patch"])
+    np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=2e-5)
+    assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
+    assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
+    np.testing.assert_allclose(out.mean(axis=(0, 1)), g["out_chanmean"], atol=2e-3)
     s.close()

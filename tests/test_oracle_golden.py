@@ -252,3 +252,24 @@ def test_real_multistyle_matches_reference(oracle, pkg, weights):
     np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=2e-5)
     assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
     assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
+
+
+def test_real_frame_mode_matches_reference(oracle, pkg, weights):
+    """use_Global=False on the reference's default inputs (plum_flower 400x564, ambush_4 frame 12 padded to 576x1152; the
+    inputs are the ones stored in real_default.npz)."""
+    g, gin = load_golden("real_frame_mode"), load_golden("real_default")
+    tid = int(g["transfer_id"])
+    oracle.set_conv_backend("torch")
+    try:
+        o = oracle.Stylization(weights, use_Global=False)
+        o.prepare_style(decode_png(gin["style_png"]))
+        padded = oracle.reflect_pad(decode_png(gin["frame%d_png" % tid]), 576, 1152)
+        pre = o.transfer(padded, return_preclamp=True)[0][64:500, 64:1088]
+        out = o.transfer(padded)[64:500, 64:1088]
+    finally:
+        oracle.set_conv_backend("numpy")
+    assert_pre_close(pre[::4, ::4], g["pre_grid"])
+    assert_pre_close(pre[186:250, 480:544], g["pre_patch"])
+    np.testing.assert_allclose(pre.mean(axis=(0, 1)), g["pre_chanmean"], atol=2e-5)
+    assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
+    assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
