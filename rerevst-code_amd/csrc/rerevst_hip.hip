@@ -269,7 +269,7 @@ int debug_verify(rrv_handle h, const char* where) {
     }
     if (recs.empty()) return RRV_OK;
     unsigned* d_cnt = nullptr;
-    RCHK(dmalloc(h, (void**)&d_cnt, recs.size() * 2 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void**)&d_cnt, recs.size() * 2 * sizeof(unsigned)));      // the checker's own scratch: not subject to rrv_debug_fail_alloc
     HIPCHK(hipMemset(d_cnt, 0, recs.size() * 2 * sizeof(unsigned)));
     for (size_t i = 0; i < recs.size(); ++i)
         hipLaunchKernelGGL(dbg_check_k, dim3(64), dim3(256), 0, h->streams[0], (const float*)recs[i].base, (const float*)ptrs[i], recs[i].B, recs[i].H, recs[i].W,
