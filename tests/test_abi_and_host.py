@@ -85,11 +85,13 @@ def test_bench_kernel_name_mapping_and_traffic_lookup():
     spec.loader.exec_module(b)
     assert b.rocprof_name("conv_wino<E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2>") == "void conv_wino_split_k<54, 0>(ConvP)"
     assert b.rocprof_name("conv_wino<E_RELU | E_POOL>") == "void conv_wino_split_k<65, 0>(ConvP)"
-    assert b.rocprof_name("conv_upw<E_LRELU>") == "void conv_wino_k<2, 0, 4, 1, 0>(ConvP)"
-    assert b.rocprof_name("conv_upw_sc<E_LRELU | E_NORM1>") == "void conv_wino_k<6, 0, 4, 1, 1>(ConvP)"
+    assert b.rocprof_name("conv_upw<E_LRELU>") == "void conv_wino_k<2, 0, 4, 1, 0, 0>(ConvP)"
+    assert b.rocprof_name("conv_upw_sc<E_LRELU | E_NORM1>") == "void conv_wino_k<6, 0, 4, 1, 1, 0>(ConvP)"
     assert b.rocprof_name("conv_mfma<128,1,0>") == "void conv_mfma_k<128, 1, 0, 0, 0, 1>(ConvP)"
-    t = b.measured_traffic("conv_wino<E_RELU>")
-    assert t is None or t > 1e6
+    for size, ms in ((512, 0), (256, 0), (1024, 0), (1024, 4)):        # every configuration has a committed counter pass: never null
+        t = b.measured_traffic("conv_upw_sc<E_LRELU | E_NORM1>", size, ms)
+        assert t is not None and t > 1e8, (size, ms, t)
+    assert b.measured_traffic("conv_wino<E_RELU>") > 1e6
     assert b.measured_traffic("no_such_kernel<1>") is None
 
 
