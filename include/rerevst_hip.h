@@ -211,6 +211,11 @@ int rrv_set_grid_share(rrv_handle h, int share);
  * input / the output only, the other direction staged.  Same results bit for bit. */
 int rrv_set_host_io(rrv_handle h, int mode);
 
+/* Debugging aid: activation tensor `index` (0..8 encoder c11 p1 c21 p2 c31 c32 c33 p3 c41, 9..22 decoder d f1 f2 f3 xs4 a4
+ * o4 xs3 a3 o3 xs2 a2 o2 dpart) of workspace slot `slot` for frames of H x W, first image, ring layout [H'+2][W'+2][C],
+ * copied to the host after a full synchronisation.  *floats receives its size (nothing is copied when cap is smaller). */
+int rrv_debug_copy_tensor(rrv_handle h, int slot, int index, int H, int W, float* host, size_t cap, size_t* floats);
+
 /* Stream-ordered use of the *_device entries from a caller that produces / consumes the buffers on its own HIP
  * stream (e.g. torch.cuda.current_stream().cuda_stream): see ORDERING above.  enable = 0 switches it off. */
 int rrv_set_caller_stream(rrv_handle h, void* hip_stream, int enable);

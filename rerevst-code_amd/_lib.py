@@ -56,6 +56,7 @@ SYMBOLS = {
     "rrv_sync": (C.c_int, [C.c_void_p]),
     "rrv_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_set_host_io": (C.c_int, [C.c_void_p, C.c_int]),
+    "rrv_debug_copy_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rrv_set_grid_share": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_set_caller_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rrv_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -418,6 +418,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         for (int dx = 0; dx < PW; ++dx) col_pass(va, dx);
 #pragma unroll
         for (int r = 0; r < PW; ++r) row_pass(va, r);
+        __syncthreads();      // raw(0) has been read by every wave before the first chunk requests raw(2) into its buffer (see conv_wino_split_k)
     }
     while (have) {
         const int e_y0 = (cur.ty + p.ty0) * 16, e_x0 = (cur.tx + p.tx0) * 16, e_b = cur.b, e_ntile = cur.nt;
@@ -518,6 +519,9 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         }
         tick(5);                              // epilogue issue
     }
+    // the LDS-DMA transfers the last item issued into the free buffers must land before the workgroup returns its LDS
+    // (see conv_wino_split_k: another stream's workgroup may start on this CU at once)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((ABL & 16) && lane == 0) {
         long long* dbg = p.dbg;   // microbench only
 #pragma unroll

@@ -244,6 +244,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         for (int dx = 0; dx < 4; ++dx) col_pass(d, va, dx);
 #pragma unroll
         for (int rl = 0; rl < 2; ++rl) row_pass(va, rl);
+        // Every wave has read its raw(0) patch before ANY wave's first chunk requests raw(2) into the same LDS buffer.
+        // (Without this barrier a wave delayed past the LDS-DMA latency — another stream's kernel competing for its SIMD —
+        // read a patch partly overwritten by chunk 2's channels: one frame in ~10^4..10^5 slightly wrong with two or
+        // more streams in flight; found and located in round 3 with tools/device_stream_stress.py / layer_hunt.py.)
+        __syncthreads();
     }
     while (have) {
         const int e_y0 = (cur.ty + p.ty0) * 16, e_x0 = (cur.tx + p.tx0) * 16, e_b = cur.b, e_ntile = cur.nt;
@@ -383,4 +388,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
             }
         }
     }
+    // The last two chunks of the LAST item re-requested tiles into the free LDS buffers (nobody reads them): those
+    // LDS-DMA transfers must land before the workgroup gives its LDS back — a workgroup of another stream's kernel can
+    // start on this CU at once, and a stray LDS-DMA write then lands in ITS shared memory (found in round 3: one frame
+    // in ~10^5 wrong with two or more streams in flight, tools/device_stream_stress.py / layer_hunt.py).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

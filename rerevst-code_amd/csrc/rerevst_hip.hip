@@ -96,6 +96,7 @@ struct rrv_ctx {
     hipStream_t stream = nullptr;              // stream the launch helpers use (= streams[slot in use])
     hipStream_t streams[RRV_MAX_SLOTS] = {nullptr};
     int n_slots = 2, next_slot = 0, last_slot = 0;   // transfer calls alternate over n_slots (stream, workspace) pairs
+    int slot_override = -1;                          // look-ahead tickets: THIS (stream, workspace) pair, whatever rrv_set_pipeline says
     hipEvent_t slot_ev[RRV_MAX_SLOTS] = {nullptr};   // ordering against the caller's stream (rrv_set_caller_stream)
     hipStream_t caller_stream = nullptr; bool caller_sync = false;
     int user_style = -1;                             // style the plain transfer entries use (first computed / last set_state)
@@ -849,7 +850,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
     // consecutive calls alternate over two (stream, workspace) pairs so that the tail / store burst of
     // one batch's kernels overlaps the next batch's kernels (frames are independent)
-    const int slot = (h->n_slots > 1 && !h->profiling) ? h->next_slot : 0;
+    const int slot = h->slot_override >= 0 ? h->slot_override : (h->n_slots > 1 && !h->profiling) ? h->next_slot : 0;
     h->next_slot = (slot + 1) % h->n_slots;
     h->last_slot = slot;
     struct StreamScope { rrv_handle h; ~StreamScope() { h->stream = h->streams[0]; } } scope{h};
@@ -2056,8 +2057,9 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
     // measured 230-260 frames/s against 551.)
     RCHK(ensure_active(h));
     HIPCHK(hipMemcpyAsync(st.d_in, src, fb, hipMemcpyHostToDevice, cs));
-    h->next_slot = slot;
+    h->slot_override = slot;       // (rrv_set_pipeline(1) would otherwise put the kernels on stream 0 and the event below on an idle stream)
     const int rc0 = transfer_device(h, st.d_in, 1, H, W, out_pin ? out : st.pin_out);
+    h->slot_override = -1;
     h->next_slot = 0;
     if (rc0 != RRV_OK) return rc0;
     HIPCHK(hipEventRecord(st.out_done, cs));
@@ -2361,6 +2363,26 @@ int rrv_set_host_io(rrv_handle h, int mode) {
     for (int i = 0; i < 4; ++i) RCHK(retire_ticket(h, i));
     RCHK(sync_all(h));
     h->host_io = mode;
+    return RRV_OK;
+}
+
+// Debugging aid (race hunting, tools/device_stream_stress.py): copy activation tensor `index` of workspace slot `slot`
+// (0..8 encoder c11 p1 c21 p2 c31 c32 c33 p3 c41, 9..22 decoder d f1 f2 f3 xs4 a4 o4 xs3 a3 o3 xs2 a2 o2 dpart) of the plan
+// for (H, W) to the host, ring layout, first image.  *floats = its size; nothing is copied when cap is too small.
+int rrv_debug_copy_tensor(rrv_handle h, int slot, int index, int H, int W, float* host, size_t cap, size_t* floats) {
+    if (!h || slot < 0 || slot >= RRV_MAX_SLOTS || index < 0 || index > 22 || !floats) return RRV_E_ARG;
+    HIPCHK(hipSetDevice(h->dev));
+    RCHK(sync_all(h));
+    const Tens* t = nullptr;
+    for (int k = 0; k < 2 && !t; ++k) {
+        EncPlan& e = h->enc_frame[slot][k]; DecPlan& d = h->dec[slot][k];
+        const Tens* all[23] = {&e.c11, &e.p1, &e.c21, &e.p2, &e.c31, &e.c32, &e.c33, &e.p3, &e.c41,
+                               &d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2, &d.dpart};
+        if (index < 9 ? (e.H == H && e.W == W && e.B > 0) : (d.H == H / 8 * 8 && d.W == W / 8 * 8 && d.B > 0)) t = all[index];
+    }
+    if (!t || !t->p) return fail(h, RRV_E_STATE, "debug_copy_tensor: no such tensor in this slot");
+    *floats = t->img_floats();
+    if (host && cap >= *floats) HIPCHK(hipMemcpy(host, t->p, *floats * sizeof(float), hipMemcpyDeviceToHost));
     return RRV_OK;
 }
 

@@ -248,6 +248,14 @@ class Stylization():
         """Persistent grids use 1/share of the CUs (share 1..4): launches of several streams run side by side."""
         self._chk(self._lib.rrv_set_grid_share(self._h, int(share)))
 
+    def debug_tensor(self, slot, index, H, W):
+        """Activation tensor `index` of workspace slot `slot` for H x W frames (rrv_debug_copy_tensor), flat float32."""
+        n = C.c_size_t(0)
+        self._chk(self._lib.rrv_debug_copy_tensor(self._h, int(slot), int(index), int(H), int(W), None, 0, C.byref(n)))
+        out = np.empty(n.value, np.float32)
+        self._chk(self._lib.rrv_debug_copy_tensor(self._h, int(slot), int(index), int(H), int(W), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
+
     def set_host_io(self, mode):
         """0 (default): staged H2D / D2H copies; 1: zero copy — kernels read / write page-locked host memory directly."""
         self._chk(self._lib.rrv_set_host_io(self._h, int(mode)))

@@ -327,6 +327,13 @@ def test_async_tickets_equal_plain_transfer(hip, pkg, oracle):
         np.testing.assert_array_equal(batch[k], ref[2 + k])
     odd = pkg.synth_frame(940, 67, 93, kind="noise")               # 8*(H/8) x 8*(W/8) output
     np.testing.assert_array_equal(hip.result(hip.transfer_async(odd)), hip.transfer(odd))
+    hip.set_pipeline(1)                                            # tickets keep their own streams whatever the pipeline depth is
+    try:                                                           # (found by tools/soak_host_entries.py: the completion event sat on an idle stream)
+        tickets = [hip.transfer_async(f) for f in frames[:4]]
+        for k in range(4):
+            np.testing.assert_array_equal(hip.result(tickets[k]), ref[k])
+    finally:
+        hip.set_pipeline(2)
     t = hip.transfer_async(frames[0])
     np.testing.assert_array_equal(hip.result(t), ref[0])
     np.testing.assert_array_equal(hip.result(t), ref[0])           # waiting twice is harmless
@@ -456,3 +463,27 @@ def test_destroy_returns_the_device_memory(pkg, weights, oracle):
     for _ in range(3):
         free2 = cycle()
     assert free1 - free2 < (8 << 20), (free1, free2)      # < 8 MiB drift over three more create/destroy cycles (one handle holds ~1.3 GB)
+
+
+def test_random_sequence_of_host_entries_is_bit_exact():
+    """tools/soak_host_entries.py, short form: a random mix of transfer / transfer_batch (pageable and page-locked) /
+    transfer_frames / look-ahead tickets collected in any order / host-I/O modes / pipeline depths over three frame
+    geometries — every output bit-identical to the plain one-frame transfer()."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("soak_host_entries", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_host_entries.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(iters=250, seed=11, verbose=False)
+
+
+def test_streams_in_flight_do_not_disturb_each_other():
+    """tools/device_stream_stress.py, short form: 24 000 small frames, one per launch, on four streams with full-size
+    grids (the most kernel-to-kernel overlap the library can produce) — every frame bit-identical to its single-stream
+    result.  Regression test of the round-3 find: a missing barrier between the first work item's prologue and its first
+    LDS-DMA in the transform-domain kernels made about one such frame in 10^4 slightly wrong."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("device_stream_stress", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "device_stream_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(iters=2000, slots=4, share=1, verbose=False) == 0
+    assert mod.run(iters=700, slots=2, share=1, verbose=False) == 0

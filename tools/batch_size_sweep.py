@@ -9,14 +9,14 @@ m.prepare_style(pkg.synth_style(512, 512, kind="noise", seed=7)); m.clean()
 for i in (0, 8, 16): m.add(pkg.synth_frame(i, S, S, kind="noise"))
 m.compute()
 dev = torch.device("cuda", 0)
-NB = 32
+NB = 32 if S < 1024 else 8
 frames = torch.from_numpy(np.stack([V.reflect_pad(pkg.synth_frame(i % 8, S, S, kind="noise"), P, P) for i in range(NB)])).to(dev)
 out = torch.empty((2 * NB, P, P, 3), dtype=torch.float32, device=dev)
 torch.cuda.synchronize()
 for slots in (1, 2):
     m.set_pipeline(slots)
-    for B in (4, 8, 12, 16, 24, 32):
-        n = max(4, 256 // B)
+    for B in ((1, 2, 3, 4, 6, 8) if S >= 1024 else (4, 8, 12, 16, 24, 32)):
+        n = max(4, (256 if S < 1024 else 64) // B)
         for i in range(3): m.transfer_batch_device(frames.data_ptr(), B, P, P, out[(i & 1) * NB:].data_ptr())
         m.sync()
         t0 = time.perf_counter()
