@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         par_ntile = cur.nt;
         __syncthreads();
         next_patch();
+        __syncthreads();      // round-3 fix, as in the library kernels: raw(0) is read by every wave before the first chunk's LDS-DMA reuses its buffer
     }
     if (ABL & 16) tl_t = clock64();
     while (have) {

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         for (int dx = 0; dx < PW; ++dx) col_pass(va, dx);
 #pragma unroll
         for (int r = 0; r < PW; ++r) row_pass(va, r);
+        __syncthreads();      // round-3 fix, as in the library kernels: raw(0) is read by every wave before the first chunk's LDS-DMA reuses its buffer
     }
     while (have) {
         const int e_y0 = (cur.ty + p.ty0) * 16, e_x0 = (cur.tx + p.tx0) * 16, e_b = cur.b, e_ntile = cur.nt;

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_ab_k(const ConvP p) {
         for (int dx = 0; dx < 4; ++dx) col_pass(d, va, dx);
 #pragma unroll
         for (int rl = 0; rl < 2; ++rl) row_pass(va, rl);
+        __syncthreads();      // round-3 fix, as in the library kernels: raw(0) is read by every wave before the first chunk's LDS-DMA reuses its buffer
     }
     while (have) {
         const int e_y0 = (cur.ty + p.ty0) * 16, e_x0 = (cur.tx + p.tx0) * 16, e_b = cur.b, e_ntile = cur.nt;
