@@ -251,3 +251,14 @@ def test_multistyle_command_line_driver_end_to_end(tmp_path, pkg, weights):
     for i in range(5):
         got = D.read_image_bgr(str(tmp_path / "out" / ("%d.png" % i)))
         assert np.abs(got.astype(np.int32) - D.to_uint8(ref[i]).astype(np.int32)).max() <= 1     # batched vs per-frame call order: same arithmetic, uint8 rounding ties
+
+
+def test_random_sequence_of_multistyle_entries_is_bit_exact():
+    """tools/soak_multistyle.py, short form: transfer_many over random features / weights / group sizes / pipeline depths,
+    single transfers and blended full-frame transfers in between — every batched frame bit-identical to the per-feature
+    transfer() (state sets per slot and per image, blends and folds on two streams)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("soak_multistyle", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_multistyle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(iters=600, seed=5, verbose=False)
