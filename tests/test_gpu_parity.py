@@ -396,3 +396,30 @@ def test_any_frame_size_floors_like_the_reference(hw, pkg, oracle, weights):
     g2 = fm.transfer(frames[1])
     assert g2.shape == (Ho, Wo, 3) and np.abs(g2 - fo.transfer(frames[1])).max() <= IMG_ATOL
     fm.close()
+
+
+def test_random_frame_sizes_against_the_oracle(pkg, oracle, weights):
+    """A fuzz over frame sizes (8 .. 150 in both directions, seeded): every size goes through transfer(), the look-ahead
+    ticket and — unpadded — the pad / crop entry, against the oracle at the stated tolerances; the three entries agree
+    bit for bit with each other where they compute the same thing."""
+    rng = np.random.default_rng(2024)
+    style = pkg.synth_style(56, 72, kind="smooth", seed=23)
+    sampled = [pkg.synth_frame(i, 53, 47, kind="smooth", seed=61) for i in range(2)]
+    s, o = _prep_pair(pkg, oracle, weights, style, sampled)
+    o.set_state(s.get_state())
+    sizes = [(8, 8), (8, 150), (150, 8), (16, 17), (129, 127)] + [(int(rng.integers(8, 151)), int(rng.integers(8, 151))) for _ in range(9)]
+    for H, W in sizes:
+        f = pkg.synth_frame(int(rng.integers(1000)), H, W, kind="noise", seed=62)
+        ref_pre, ref = o.transfer(f, return_preclamp=True)[0], o.transfer(f)
+        got = s.transfer(f)
+        assert got.shape == ref.shape == (H // 8 * 8, W // 8 * 8, 3), (H, W)
+        assert np.abs(got - ref).max() <= IMG_ATOL, (H, W)
+        assert_pre_close(s.preclamp(H // 8 * 8, W // 8 * 8), ref_pre, "pre-clamp at %dx%d" % (H, W))
+        np.testing.assert_array_equal(s.result(s.transfer_async(f)), got)
+        PH, PW = oracle.padded_size(H), oracle.padded_size(W)
+        crop = s.transfer_frames([f])[0]                                   # pad to (PH, PW) on the device, stylize, crop
+        assert crop.shape == (H, W, 3)
+        full = s.transfer(oracle.reflect_pad(f, PH, PW))
+        np.testing.assert_array_equal(crop, full[64:64 + H, 64:64 + W])
+        assert np.abs(crop - o.transfer(oracle.reflect_pad(f, PH, PW))[64:64 + H, 64:64 + W]).max() <= IMG_ATOL, (H, W)
+    s.close()
