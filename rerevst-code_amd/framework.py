@@ -37,6 +37,52 @@ def _u8_image(img, what):
     return a
 
 
+class _OutputPool:
+    """Output arrays of the host entries come out of recycled page-locked blocks: the reference's call surface returns a
+    fresh array per frame (framework.py:40-49), and a fresh pageable 5 MB array costs ~0.2 ms of page faults plus a
+    staging copy per call — a tenth of a one-frame transfer().  A block goes back to the pool when the LAST array that
+    views it dies (numpy collapses the base of every derived view onto the lease object below), so a recycled block is
+    never visible to the caller.  Bounded: beyond `cap_bytes` of blocks handed out or parked, arrays are plain numpy."""
+    cap_bytes = 2 << 30
+    keep_per_size = 8
+
+    def __init__(self):
+        self.free = {}            # nbytes -> [address]
+        self.live = 0             # bytes of blocks in existence (handed out + parked)
+
+    def _give_back(self, lib, addr, nbytes):
+        lst = self.free.setdefault(nbytes, [])
+        if len(lst) < self.keep_per_size:
+            lst.append(addr)
+        else:
+            lib.rrv_host_free(C.c_void_p(addr))
+            self.live -= nbytes
+
+    def empty(self, shape, dtype=np.float32):
+        import weakref
+        dt = np.dtype(dtype)
+        count = int(np.prod(shape))
+        nbytes = max(count * dt.itemsize, 1)
+        lib = _lib.load()
+        lst = self.free.get(nbytes)
+        if lst:
+            addr = lst.pop()
+        else:
+            if self.live + nbytes > self.cap_bytes:
+                return np.empty(shape, dtype=dt)
+            ptr = C.c_void_p()
+            if lib.rrv_host_alloc(nbytes, C.byref(ptr)) != 0:
+                return np.empty(shape, dtype=dt)
+            addr = ptr.value
+            self.live += nbytes
+        lease = (C.c_char * nbytes).from_address(addr)
+        weakref.finalize(lease, self._give_back, lib, addr, nbytes)
+        return np.frombuffer(lease, dtype=dt, count=count).reshape(shape)
+
+
+_outputs = _OutputPool()
+
+
 class Stylization():
     """``Stylization(checkpoint, cuda=True, use_Global=True)`` (test/framework.py:57).
 
@@ -146,7 +192,7 @@ class Stylization():
         blended first (stylization.py:94-100)."""
         a = _u8_image(frame, "frame")
         H, W = a.shape[:2]
-        out = np.empty((H // 8 * 8, W // 8 * 8, 3), dtype=np.float32)     # the max pools floor the size, as in the reference
+        out = _outputs.empty((H // 8 * 8, W // 8 * 8, 3))     # the max pools floor the size, as in the reference
         if not self.use_Global:
             self._chk(self._lib.rrv_transfer_frame_mode(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p)))
             return out
@@ -179,7 +225,7 @@ class Stylization():
         H, W = a.shape[:2]
         oshape = (H // 8 * 8, W // 8 * 8, 3)
         if out is None:
-            out = np.empty(oshape, dtype=np.float32)
+            out = _outputs.empty(oshape)
         elif out.dtype != np.float32 or out.shape != oshape or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous float32 array of shape %r" % (oshape,))
         t = C.c_long(-1)
@@ -210,7 +256,7 @@ class Stylization():
         B, H, W, _ = a.shape
         oshape = (B, H // 8 * 8, W // 8 * 8, 3)
         if out is None:
-            out = np.empty(oshape, dtype=np.float32)
+            out = _outputs.empty(oshape)
         elif out.dtype != np.float32 or out.shape != oshape or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous float32 array of shape %r" % (oshape,))
         self._chk(self._lib.rrv_transfer_batch(self._h, a.ctypes.data_as(C.c_void_p), B, H, W, out.ctypes.data_as(C.c_void_p)))
@@ -226,7 +272,7 @@ class Stylization():
             a = np.stack([_u8_image(f, "frame") for f in frames])
         B, H, W, _ = a.shape
         if out is None:
-            out = np.empty((B, H, W, 3), dtype=np.float32)
+            out = _outputs.empty((B, H, W, 3))
         elif out.dtype != np.float32 or out.shape != (B, H, W, 3) or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous float32 array of shape %r" % ((B, H, W, 3),))
         self._chk(self._lib.rrv_transfer_frames(self._h, a.ctypes.data_as(C.c_void_p), B, H, W, out.ctypes.data_as(C.c_void_p)))
@@ -299,7 +345,7 @@ class Stylization():
 
     def preclamp(self, H, W):
         """Pre-clamp network output of the last transfer, NHWC RGB normalised units."""
-        out = np.empty((H, W, 3), dtype=np.float32)
+        out = _outputs.empty((H, W, 3))
         self._chk(self._lib.rrv_get_preclamp(self._h, out.ctypes.data_as(C.c_void_p), H, W))
         return out
 
@@ -348,7 +394,7 @@ class MultiStyleStylization(Stylization):
     def transfer(self, cur_feature, style_weight=[1.], out=None):
         H, W = cur_feature.shape[0] // 8 * 8, cur_feature.shape[1] // 8 * 8
         if out is None:
-            out = np.empty((H, W, 3), dtype=np.float32)
+            out = _outputs.empty((H, W, 3))
         elif out.dtype != np.float32 or out.shape != (H, W, 3) or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous float32 array of shape %r" % ((H, W, 3),))
         w = (C.c_float * len(style_weight))(*[float(v) for v in style_weight])
@@ -362,7 +408,7 @@ class MultiStyleStylization(Stylization):
         H, W = features[0].shape[0] // 8 * 8, features[0].shape[1] // 8 * 8
         ns = len(style_weights[0])
         if out is None:
-            out = np.empty((n, H, W, 3), dtype=np.float32)
+            out = _outputs.empty((n, H, W, 3))
         elif out.dtype != np.float32 or out.shape != (n, H, W, 3) or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous float32 array of shape %r" % ((n, H, W, 3),))
         ids = (C.c_int * n)(*[f.id for f in features])
