@@ -68,6 +68,10 @@ class _OutputPool:
         if lst:
             addr = lst.pop()
         else:
+            for size in sorted(self.free, reverse=True):          # over the cap: parked blocks of other sizes go first
+                while self.free[size] and self.live + nbytes > self.cap_bytes:
+                    lib.rrv_host_free(C.c_void_p(self.free[size].pop()))
+                    self.live -= size
             if self.live + nbytes > self.cap_bytes:
                 return np.empty(shape, dtype=dt)
             ptr = C.c_void_p()
