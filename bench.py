@@ -175,14 +175,21 @@ def roofline_and_kernels(rows, nprof, frames_per_step, size, multistyle=0):
     executed = fx / t_ms / 1e9
     mf = [a for nm, a in agg.items() if nm.startswith(("conv_mfma", "conv_wino", "conv_upw"))]
     roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+            "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "frac_basis": "executed",
+            "frac_executed": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+            "frac_algorithmic": round(fl / t_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": measured_traffic(dom[0], size, multistyle),
             "traffic_source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration; "
-                              "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024)" % os.path.basename(traffic_file(size, multistyle)),
+                              "bytes per launch = (F*FETCH_SIZE + WRITE_SIZE)*1024 with the per-kernel factor F of "
+                              "profiles/r03_fetch_size_calibration.txt: 1 for the 64-byte LDS-DMA rows of the transform-domain "
+                              "kernels, 2 for >= 128-byte contiguous reads; `fetch_factor` in every entry of the file)"
+                              % os.path.basename(traffic_file(size, multistyle)),
             "algorithmic_bytes_per_launch": round(by / n),
             "algorithmic_tflops": round(fl / t_ms / 1e9, 2), "algorithmic_speedup": round(fl / fx, 3),
-            "note": "achieved/frac = FLOPs the kernel EXECUTES / HIP-event time / fp32-MFMA peak; algorithmic_tflops = FLOPs of "
-                    "the reference's direct 3x3 convolution over the same time (transform-domain kernels multiply 2.25x-4x less)",
+            "note": "achieved / frac / frac_executed = FLOPs the kernel EXECUTES / HIP-event time / fp32-MFMA peak (what the matrix "
+                    "pipe issues); frac_algorithmic / algorithmic_tflops = FLOPs of the reference's direct 3x3 convolution "
+                    "(SURVEY 8(d)) over the same time — above 1 because the transform-domain kernels multiply 2.25x-4x less, not "
+                    "because work is skipped",
             "avg_launch_ms": round(t_ms / n, 5), "share_of_gpu_time": round(t_ms / tot_ms, 3),
             "all_matrix_kernels_executed_tflops": round(sum(a[4] for a in mf) / sum(a[1] for a in mf) / 1e9, 2),
             "all_matrix_kernels_executed_frac": round(sum(a[4] for a in mf) / sum(a[1] for a in mf) / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
@@ -261,6 +268,25 @@ def cpu_baseline(setup, unit, what, budget_s=25.0):
             "one_core_value": round(1.0 / med1, 4), "one_core_sample": "median of %d, 1 thread" % n1}
 
 
+def sub_leg(extra_args, timeout_s=600):
+    """One of the other BASELINE configurations as a short run of this script in a child process (after the timed headline
+    region, same GPU): returns the few fields the headline line carries as extras, or {"error": ...}."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-extras"] + extra_args
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "RRV_BENCH_FORCE_DIST")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        roof = d.get("roofline") or {}
+        return {"frames_per_s": d["value"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
+                "workload": d["config"]["workload"], "frames_per_step": d["config"]["frames_per_step_per_gpu"],
+                "dominant_kernel": roof.get("kernel"), "frac_executed": roof.get("frac_executed"), "frac_algorithmic": roof.get("frac_algorithmic"),
+                "all_matrix_kernels_executed_frac": roof.get("all_matrix_kernels_executed_frac"),
+                "end_to_end_frames_per_s": d.get("end_to_end_frames_per_s"), "feature_cache_frames_per_s": d.get("feature_cache_frames_per_s")}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +298,7 @@ def main():
     ap.add_argument("--multistyle", type=int, default=0, help="S > 0: BASELINE config 5, S-style interpolation, decoder only per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short 256x256 (config 2) and 4-style 1024x1024 (config 5) legs appended to the default run")
     ap.add_argument("--profile-steps", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=2, help="sub-batches in flight per GPU (1 or 2 HIP streams)")
     ap.add_argument("--pageable", action="store_true", help="time the host entry with pageable caller arrays instead of page-locked ones")
@@ -329,6 +356,9 @@ def main():
     else:
         model = pkg.Stylization(weights, cuda=True, device=local)
     model.set_pipeline(args.pipeline)
+    MS_GROUP = 1      # frames per launch sequence of rrv_transfer_features_batch (the library's default, set explicitly: what config.sub_batch reports)
+    if NS:
+        model.set_multistyle_group(MS_GROUP)
     if os.environ.get("RRV_BENCH_GRID_SHARE"):       # experiment knob: every launch takes 1/n of the CUs (DESIGN 4 "One frame per call")
         model.set_grid_share(int(os.environ["RRV_BENCH_GRID_SHARE"]))
 
@@ -452,7 +482,7 @@ def main():
                "config": {"workload": what, "entry": ("rrv_transfer_features_batch: relu4_1 features in HBM -> float32 frames in %s host memory" if NS else
                                                       "rrv_transfer_batch: uint8 frames in %s host memory -> float32 frames in the same (H2D + kernels + D2H)")
                                                % ("pageable" if args.pageable else "page-locked"),
-                          "frames_per_step_per_gpu": B, "sub_batch": max(1, min(4, -(-256 // (-(-(P // 8) // 16) ** 2)))) if NS else max(1, min(32, B, (8 * 640 * 640) // (P * P))), "batches_in_flight": args.pipeline,
+                          "frames_per_step_per_gpu": B, "sub_batch": MS_GROUP if NS else max(1, min(32, B, (8 * 640 * 640) // (P * P))), "batches_in_flight": args.pipeline,
                           "sampled_frames": len(video.sample_indices_multistyle(NF, 16) if NS else video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
                "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu,
@@ -560,6 +590,45 @@ def main():
                     model.transfer_batch(h_in[i % n_batches], out=h_out[i & 1])
                 out[key] = round(nr2 * B / (time.perf_counter() - t1), 1)
             model.set_host_io(0)
+        # (5) SURVEY 8(f)4, the driver's file -> file rate: PNG frames on disk -> decode (worker threads) -> transfer_frames ->
+        # encode / write (worker threads), the reference script's whole loop (generate_real_video.py:152-171) without its
+        # one-off preparation.  Smooth synthetic frames (white noise is the codecs' worst case, not video).
+        if world == 1 and not args.no_extras and not NS and os.environ.get("RRV_BENCH_NO_DRIVER") != "1":
+            try:
+                import shutil
+                import tempfile
+                drv = importlib.import_module("rerevst-code_amd.driver")
+                base = tempfile.mkdtemp(prefix="rrv_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+                try:
+                    nfr = 192 if S <= 512 else 48
+                    os.makedirs(os.path.join(base, "in"))
+                    paths = [os.path.join(base, "in", "f%04d.png" % i) for i in range(nfr)]
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(drv.default_io_threads()) as ex:
+                        list(ex.map(lambda a: drv.write_image_bgr(a[0], pkg.synth_frame(a[1], S, S, kind="smooth")), zip(paths, range(nfr))))
+                    drv.write_image_bgr(os.path.join(base, "style.png"), pkg.synth_style(512, 512, kind="smooth", seed=7))
+                    st = {}
+                    drv.stylize_files(model, os.path.join(base, "style.png"), paths, os.path.join(base, "out"), chunk=32, log=lambda *_: None, stats=st)
+                    out["driver_png_to_png_frames_per_s"] = round(st["frames_per_s"], 1)
+                    out["driver_png_to_png"] = {"frames": nfr, "io_threads": st["io_threads"], "host_cores": os.cpu_count(), "chunk": 32,
+                                                "gpu_call_seconds": round(st["gpu_call_s"], 3), "stage_seconds": round(st["frames_s"], 3),
+                                                "preparation_seconds": round(st["prep_s"], 3),
+                                                "what": "%dx%d PNG files (tmpfs) -> stylized PNG files, decode / transfer_frames / encode overlapped" % (S, S)}
+                finally:
+                    shutil.rmtree(base, ignore_errors=True)
+            except Exception as e:
+                out["driver_png_to_png_frames_per_s"] = None
+                out["driver_png_to_png"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        # BASELINE configs 2 and 5 as short legs of the SAME default invocation (the driver runs only this one), after the timed
+        # headline region: extras, never `value`.  Each is this script in a child process with its own steps / warm-up.
+        if world == 1 and not args.no_extras and not args.no_other_configs and not NS and S == 512 and not args.pageable:
+            model.close()
+            c2 = sub_leg(["--size", "256", "--steps", "8", "--warmup", "2"])
+            c5 = sub_leg(["--multistyle", "4", "--steps", "6", "--warmup", "2"])
+            out["config2"] = c2
+            out["config5"] = c5
+            out["config2_frames_per_s"] = c2.get("frames_per_s")
+            out["config5_frames_per_s"] = c5.get("frames_per_s")
         if os.environ.get("RRV_BENCH_LAYERS"):
             out["layers"] = [{"layer": k, "ms_per_frame": round(v[1] / nprof / B, 4), "tflops": round(v[2] / v[1] / 1e9, 1),
                               "tflops_executed": round(v[3] / v[1] / 1e9, 1)}

@@ -113,10 +113,12 @@ int rrv_transfer(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* ou
  * rrv_transfer_wait(ticket) blocks until `out_bgr` of that call is filled.  Up to FOUR tickets may be open (a fifth
  * submission first completes the oldest): each runs on its own stream and workspace with a quarter of the CUs per
  * launch, so four frames run side by side instead of queueing behind each other's partially filled last round of
- * workgroups, and the kernels read the frame from / write the result to page-locked host memory directly (the caller's
- * buffers if they are page-locked, the library's staging otherwise) — no copy streams.  Keeping three frames submitted
- * ahead of the one collected gives 551 frames/s at 512x512 and 1418 at 256x256 against 431 / 868 for rrv_transfer.
- * `frame_bgr` may be reused as soon as the call returns; `out_bgr` must stay valid until its ticket is waited for.
+ * workgroups.  The frame is copied to the device on the ticket's own stream (one H2D copy; no separate copy streams)
+ * and the last kernel writes the result to page-locked host memory directly (the caller's buffer if it is page-locked,
+ * the library's staging otherwise).  Keeping three frames submitted ahead of the one collected gives 551 frames/s at
+ * 512x512 and 1418 at 256x256 against 431 / 868 for rrv_transfer.
+ * `frame_bgr` may be reused as soon as the call returns (a pageable frame has been copied to staging by then; for a
+ * page-locked one the call waits for its H2D copy); `out_bgr` must stay valid until its ticket is waited for.
  * Bit-identical to rrv_transfer. */
 int rrv_transfer_async(rrv_handle h, const uint8_t* frame_bgr, int H, int W, float* out_bgr, long* ticket);
 int rrv_transfer_wait(rrv_handle h, long ticket);

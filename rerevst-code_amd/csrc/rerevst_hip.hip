@@ -467,7 +467,10 @@ int conv(rrv_handle h, const ConvCall& c) {
         const unsigned slabs = (unsigned)(w.Cout / 32) * ks;
         const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B) * slabs;
         unsigned resident = (unsigned)h->n_cus * (c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);
-        if (h->grid_share > 1) resident = (resident / h->grid_share) & ~7u;      // rrv_set_grid_share: leave CUs to the launches of the other stream
+        if (h->grid_share > 1) {      // rrv_set_grid_share: leave CUs to the launches of the other stream(s); whole XCD rows, never empty
+            resident = (resident / h->grid_share) & ~7u;      // (a small / partitioned / CU-masked device: n_cus * OCC / share < 8)
+            if (resident < 8) resident = 8;
+        }
         grid = dim3(items < resident ? items : resident, 1);
         // slabs of one pixel tile on one XCD (workgroup w runs on XCD w % 8): the raw tile is fetched once per XCD group
         p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
@@ -2057,10 +2060,15 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
     // measured 230-260 frames/s against 551.)
     RCHK(ensure_active(h));
     HIPCHK(hipMemcpyAsync(st.d_in, src, fb, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipEventRecord(st.in_done, cs));      // the frame has left the caller's buffer (waited for below when the copy reads it directly)
     h->slot_override = slot;       // (rrv_set_pipeline(1) would otherwise put the kernels on stream 0 and the event below on an idle stream)
     const int rc0 = transfer_device(h, st.d_in, 1, H, W, out_pin ? out : st.pin_out);
     h->slot_override = -1;
     h->next_slot = 0;
+    // Contract (include/rerevst_hip.h): `frame` may be reused as soon as the call returns.  A pageable frame was copied to
+    // staging above; a page-locked one is the DIRECT source of the asynchronous H2D copy, so wait for that copy (queued
+    // first on an idle stream: finished long before the launches above were) — also on the error path.
+    if (in_pin) HIPCHK(hipEventSynchronize(st.in_done));
     if (rc0 != RRV_OK) return rc0;
     HIPCHK(hipEventRecord(st.out_done, cs));
     auto& tk0 = h->tickets[set];
@@ -2071,7 +2079,8 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
 }
 
 int rrv_transfer_wait(rrv_handle h, long ticket) {
-    if (!h || ticket < 0 || ticket >= h->next_ticket) return RRV_E_ARG;
+    if (!h) return RRV_E_ARG;
+    if (ticket < 0 || ticket >= h->next_ticket) return fail(h, RRV_E_ARG, "transfer_wait: no such ticket");
     HIPCHK(hipSetDevice(h->dev));
     const int set = (int)(ticket % HOST_SETS);
     if (h->tickets[set].id != ticket) {

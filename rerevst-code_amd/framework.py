@@ -47,16 +47,19 @@ class _OutputPool:
     keep_per_size = 8
 
     def __init__(self):
+        import threading
         self.free = {}            # nbytes -> [address]
         self.live = 0             # bytes of blocks in existence (handed out + parked)
+        self.lock = threading.RLock()     # finalizers run on whichever thread drops the last reference (re-entrant: a GC pass inside empty())
 
     def _give_back(self, lib, addr, nbytes):
-        lst = self.free.setdefault(nbytes, [])
-        if len(lst) < self.keep_per_size:
-            lst.append(addr)
-        else:
-            lib.rrv_host_free(C.c_void_p(addr))
+        with self.lock:
+            lst = self.free.setdefault(nbytes, [])
+            if len(lst) < self.keep_per_size:
+                lst.append(addr)
+                return
             self.live -= nbytes
+        lib.rrv_host_free(C.c_void_p(addr))
 
     def empty(self, shape, dtype=np.float32):
         import weakref
@@ -64,21 +67,24 @@ class _OutputPool:
         count = int(np.prod(shape))
         nbytes = max(count * dt.itemsize, 1)
         lib = _lib.load()
-        lst = self.free.get(nbytes)
-        if lst:
-            addr = lst.pop()
-        else:
-            for size in sorted(self.free, reverse=True):          # over the cap: parked blocks of other sizes go first
-                while self.free[size] and self.live + nbytes > self.cap_bytes:
-                    lib.rrv_host_free(C.c_void_p(self.free[size].pop()))
-                    self.live -= size
-            if self.live + nbytes > self.cap_bytes:
-                return np.empty(shape, dtype=dt)
+        with self.lock:
+            lst = self.free.get(nbytes)
+            addr = lst.pop() if lst else None
+            if addr is None:
+                for size in sorted(self.free, reverse=True):          # over the cap: parked blocks of other sizes go first
+                    while self.free[size] and self.live + nbytes > self.cap_bytes:
+                        lib.rrv_host_free(C.c_void_p(self.free[size].pop()))
+                        self.live -= size
+                if self.live + nbytes > self.cap_bytes:
+                    return np.empty(shape, dtype=dt)
+                self.live += nbytes               # reserved before the allocation (released below if it fails)
+        if addr is None:
             ptr = C.c_void_p()
             if lib.rrv_host_alloc(nbytes, C.byref(ptr)) != 0:
+                with self.lock:
+                    self.live -= nbytes
                 return np.empty(shape, dtype=dt)
             addr = ptr.value
-            self.live += nbytes
         lease = (C.c_char * nbytes).from_address(addr)
         weakref.finalize(lease, self._give_back, lib, addr, nbytes)
         return np.frombuffer(lease, dtype=dt, count=count).reshape(shape)
@@ -106,6 +112,8 @@ class Stylization():
             device = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = int(device)
         self.style_num = int(style_num)
+        self._open = {}           # ticket id -> output array of an open transfer_async(): the GPU (or the retiring host copy)
+                                  # writes into it until the ticket is collected or retired, whatever the caller keeps
         self._h = C.c_void_p()
         rc = self._lib.rrv_create(self.device, C.byref(self._h))
         if rc != 0:
@@ -132,8 +140,9 @@ class Stylization():
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.rrv_destroy(self._h)
+            self._lib.rrv_destroy(self._h)      # waits for every stream: nothing writes the open tickets' outputs after it
             self._h = None
+        self._open = {}
 
     def __del__(self):
         try:
@@ -234,11 +243,18 @@ class Stylization():
             raise ValueError("out must be a C-contiguous float32 array of shape %r" % (oshape,))
         t = C.c_long(-1)
         self._chk(self._lib.rrv_transfer_async(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p), C.byref(t)))
+        # The library owns `out` until the ticket is collected or retired: a caller that drops the ticket (an exception in
+        # its loop, `prev` overwritten) must not hand the block back to the pool under a running kernel.  Submitting
+        # ticket t retired ticket t - 4 (four staging sets), so only the last four stay referenced here.
+        self._open[t.value] = out
+        for old in [k for k in self._open if k <= t.value - 4]:
+            del self._open[old]
         return (t.value, out)
 
     def result(self, ticket):
         tid, out = ticket
         self._chk(self._lib.rrv_transfer_wait(self._h, tid))
+        self._open.pop(tid, None)
         return out
 
     # ===== device-resident entry (what bench.py times) =====

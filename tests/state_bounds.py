@@ -52,29 +52,38 @@ NORM_NAMES = ["dec.norm0", "dec.norm1", "dec.norm2", "dec.norm3", "dec.norm4", "
               "slice3.norm1", "slice3.norm2", "slice2.norm1", "slice2.norm2"]
 
 
-def state_worst(got, ref):
-    """Largest |d| / bound over the saved-state blob and where it sits (bounds: see STATE_ATOL above)."""
+def state_fields(got, ref):
+    """Per FIELD of the saved-state blob (11 norm layers x {mean, std, min(x), max(x)}, 6 filters, 4 x 2 style moments):
+    [(name, worst |d| / bound, index of that entry, got, ref)] (bounds: see STATE_ATOL above)."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    worst, where = 0.0, ""
-    def upd(g, r, name, kind):
-        nonlocal worst, where
+    rows = []
+    def add(g, r, name, kind):
         ratio = np.abs(g - r) / (STATE_ATOL[kind] + STATE_RTOL * np.abs(r))
         k = int(np.argmax(ratio))
-        if ratio[k] > worst:
-            worst, where = float(ratio[k]), "%s[%d]: got %.6e ref %.6e (atol %.0e)" % (name, k, g[k], r[k], STATE_ATOL[kind])
+        rows.append((name, float(ratio[k]), k, float(g[k]), float(r[k]), STATE_ATOL[kind]))
     o = 0
     for name, C in zip(NORM_NAMES, NORM_CH):
         gm, gr, gl, gh = (got[o + i * C:o + (i + 1) * C] for i in range(4))
         rm, rr, rl, rh = (ref[o + i * C:o + (i + 1) * C] for i in range(4))
-        upd(gm, rm, name + ".mean", "mean")
-        upd(1.0 / gr, 1.0 / rr, name + ".std", "std")
-        upd(gl / gr + gm, rl / rr + rm, name + ".min(x)", "ext")
-        upd(gh / gr + gm, rh / rr + rm, name + ".max(x)", "ext")
+        add(gm, rm, name + ".mean", "mean")
+        add(1.0 / gr, 1.0 / rr, name + ".std", "std")
+        add(gl / gr + gm, rl / rr + rm, name + ".min(x)", "ext")
+        add(gh / gr + gm, rh / rr + rm, name + ".max(x)", "ext")
         o += 4 * C
-    upd(got[o:o + 6144], ref[o:o + 6144], "filters", "other")
-    o += 6144
-    upd(got[o:], ref[o:], "style moments", "other")
-    return worst, where
+    for f in range(6):
+        add(got[o:o + 1024], ref[o:o + 1024], "Filter%d.F%d.filter" % (f // 2 + 1, f % 2 + 1), "other")
+        o += 1024
+    for k, C in enumerate((64, 128, 256, 512)):
+        add(got[o:o + C], ref[o:o + C], "style.relu%d_1.mean" % (k + 1), "other")
+        add(got[o + C:o + 2 * C], ref[o + C:o + 2 * C], "style.relu%d_1.std" % (k + 1), "other")
+        o += 2 * C
+    return rows
+
+
+def state_worst(got, ref):
+    """Largest |d| / bound over the saved-state blob and where it sits (bounds: see STATE_ATOL above)."""
+    name, ratio, k, g, r, atol = max(state_fields(got, ref), key=lambda row: row[1])
+    return ratio, "%s[%d]: got %.6e ref %.6e (atol %.0e)" % (name, k, g, r, atol)
 
 
 def assert_state_close(got, ref, what="state"):
@@ -94,25 +103,61 @@ def pre_worst(got, ref):
     return float((err / (PRE_ATOL + PRE_RTOL * np.abs(ref))).max()), float(err.max())
 
 
-def assert_state_close_conditioned(got, ref32, ref64, what="state", factor=4.0):
+def _layer_of(field):
+    """'dec.norm1.min(x)' -> 'dec.norm1': the four statistics of one normalisation layer come out of one tensor and share
+    its conditioning; a filter / a style level is its own group (21 groups)."""
+    return field.rsplit(".", 1)[0]
+
+
+def _field_limits(ref_a, ref_b, factor):
+    """Limit per field from the two references' own disagreement: a LAYER in which they disagree by more than the regular
+    bound is ill-conditioned — its fields get `factor` x the references' WORST disagreement (where in the chain the
+    amplified rounding noise surfaces differs between equally valid float32 evaluations: profiles/r04_dec4_conditioning.txt);
+    every other layer keeps max(1, factor x its own disagreement), i.e. essentially the regular bound.
+    Returns (limit per field, the references' own ratio of that field's layer)."""
+    rows = state_fields(ref_a, ref_b)
+    layer = {}
+    for name, ratio, *_ in rows:
+        layer[_layer_of(name)] = max(layer.get(_layer_of(name), 0.0), ratio)
+    worst = max(layer.values())
+    lim = {}
+    for name, *_ in rows:
+        own = layer[_layer_of(name)]
+        lim[name] = factor * worst if own > 1.0 else max(1.0, factor * own)
+    return lim, {row[0]: layer[_layer_of(row[0])] for row in rows}
+
+
+def assert_state_close_conditioned(got, ref32, ref64, what="state", factor=2.5):
     """For weight sets whose saved state is ILL-CONDITIONED in float32 (tests/golden/global_a_dec4: the reference's own
-    float32 run misses its float64 run by 30x the bound above, and its 1-thread and 8-thread runs differ by as much):
-    the distance to the exact (float64) reference state may be at most `factor` times the distance of the reference's
-    own float32 run to it (and is always allowed the regular bound)."""
-    mine, where = state_worst(got, ref64)
-    theirs, _ = state_worst(ref32, ref64)
-    lim = max(1.0, factor * theirs)
-    assert mine <= lim, "%s: %.1fx the bound from the float64 reference (reference float32 itself: %.1fx; allowed %.1fx): %s" % (what, mine, theirs, lim, where)
-    return mine, theirs
+    float32 run misses its float64 run by 30x the bound above in `Filter3.F1.filter`, 10x in `Filter3.F2.filter`, 5x in
+    `dec.norm1.mean`, and sits inside the bound everywhere else; its 1-thread and 8-thread runs differ by as much).
+    Only the layers in which the reference's own float32 run leaves the bound (3 of the 21 groups: the four statistics of a
+    normalisation layer, a filter, a style level) are widened — to `factor` times the reference's own worst miss; every
+    other layer is held to the regular bound (_field_limits).  Why 2.5 and not ~1: the miss is rounding noise amplified by
+    the dynamic filters, not a property of an implementation — two direct-form float32 restatements of the same algorithm
+    sit at 1.2x (torch conv2d) and 2.0x (nine numpy GEMMs) the reference's own worst field, and a run with EVERY
+    convolution accumulated in float64 and rounded once is still at 0.8x (profiles/r04_dec4_conditioning.txt)."""
+    lims, theirs = _field_limits(ref32, ref64, factor)
+    bad, worst = [], (0.0, "", 0.0)
+    for name, ratio, k, g, r, atol in state_fields(got, ref64):
+        if ratio > lims[name]:
+            bad.append("%s[%d]: %.1fx the bound from the float64 reference (reference float32 itself: %.1fx; allowed %.1fx)" % (name, k, ratio, theirs[name], lims[name]))
+        if ratio > worst[0]:
+            worst = (ratio, name, theirs[name])
+    assert not bad, "%s: %s" % (what, "; ".join(bad))
+    return worst[0], max(theirs.values())
 
 
-def assert_state_close_two_refs(got, ref_a, ref_b, what="state", factor=2.0):
+def assert_state_close_two_refs(got, ref_a, ref_b, what="state", factor=1.25):
     """When two float32 restatements of the SAME algorithm (the oracle with its convolutions as nine numpy GEMMs, and on
-    torch's conv2d) disagree by more than the regular bound, the entry is ill-conditioned for that input (one frame,
-    B = 1: an extremum behind the near-dead relu4_1 channels): the HIP state may then be as far from one restatement as
-    `factor` times their own disagreement (and is always allowed the regular bound)."""
-    mine, where = state_worst(got, ref_a)
-    spread, swhere = state_worst(ref_b, ref_a)
-    lim = max(1.0, factor * spread)
-    assert mine <= lim, "%s: %.1fx the bound from restatement A (the two restatements differ by %.1fx at %s; allowed %.1fx): %s" % (what, mine, spread, swhere, lim, where)
-    return mine, spread
+    torch's conv2d) disagree in a layer by more than the regular bound, that layer is ill-conditioned for that input (one
+    frame, B = 1: an extremum behind the near-dead relu4_1 channels): in THAT layer the HIP state may be as far from
+    restatement A as `factor` times their own disagreement; every other layer keeps the regular bound."""
+    lims, spread = _field_limits(ref_b, ref_a, factor)
+    bad, worst = [], 0.0
+    for name, ratio, k, g, r, atol in state_fields(got, ref_a):
+        worst = max(worst, ratio)
+        if ratio > lims[name]:
+            bad.append("%s[%d]: %.1fx the bound from restatement A (the two restatements differ by %.1fx there; allowed %.1fx)" % (name, k, ratio, spread[name], lims[name]))
+    assert not bad, "%s: %s" % (what, "; ".join(bad))
+    return worst, max(spread.values())

@@ -107,3 +107,95 @@ def test_multistyle_script_flow_with_the_oracle(tmp_path, pkg, oracle):
     for i, p in enumerate(written):
         np.testing.assert_array_equal(D.read_image_bgr(p), D.to_uint8(ref[i]))
     assert os.path.getsize(str(tmp_path / "v.avi")) > 212
+
+
+class _FramesModel:
+    """The oracle behind the HIP model's batched driver entry (`transfer_frames(frames, out=)`: unpadded in, cropped
+    out), so that the threaded chunk pipeline of stylize_files runs on CPU.  Counts the calls."""
+
+    def __init__(self, oracle, weights):
+        self.o = oracle.Stylization(weights)
+        self.O = oracle
+        self.use_Global = True
+        self.calls = []
+        for name in ("prepare_style", "clean", "add", "compute", "get_state", "set_state", "transfer"):
+            setattr(self, name, getattr(self.o, name))
+
+    def transfer_frames(self, frames, out=None):
+        frames = np.asarray(frames)
+        B, H, W, _ = frames.shape
+        self.calls.append(B)
+        if out is None:
+            out = np.empty((B, H, W, 3), np.float32)
+        PH, PW = self.O.padded_size(H), self.O.padded_size(W)
+        for b in range(B):
+            out[b] = self.o.transfer(self.O.reflect_pad(frames[b], PH, PW))[64:64 + H, 64:64 + W]
+        return out
+
+
+def _write_inputs(tmp_path, pkg, n, hw=(24, 32)):
+    src = tmp_path / "in"
+    src.mkdir()
+    frames = [pkg.synth_frame(i, hw[0], hw[1], kind="smooth") for i in range(n)]
+    for i, f in enumerate(frames):
+        D.write_image_bgr(str(src / ("f%02d.png" % i)), f)
+    style = pkg.synth_style(32, 32, kind="smooth")
+    D.write_image_bgr(str(tmp_path / "style.png"), style)
+    return src, frames, style
+
+
+def test_threaded_chunk_pipeline_equals_serial_flow(tmp_path, pkg, oracle):
+    """Decode workers -> page-locked-style input buffers -> transfer_frames per chunk -> encode workers, three rotating
+    buffer sets, ragged last chunk, AVI appended in frame order: the files equal the serial reference flow."""
+    src, frames, style = _write_inputs(tmp_path, pkg, 7)
+    model = _FramesModel(oracle, pkg.synthetic_weights(0))
+    stats = {}
+    written = D.stylize_files(model, str(tmp_path / "style.png"), D.list_frames(str(src / "*.png")), str(tmp_path / "out"),
+                              video_path=str(tmp_path / "v.avi"), fps=12, chunk=2, io_threads=3, log=lambda *_: None, stats=stats)
+    assert model.calls == [2, 2, 2, 1] and stats["frames"] == 7 and stats["io_threads"] == 3
+    V = importlib.import_module("rerevst-code_amd.video")
+    ref = V.stylize_video(oracle.Stylization(pkg.synthetic_weights(0)), frames, style)
+    assert [os.path.basename(p) for p in written] == ["f%02d.png" % i for i in range(7)]
+    for i, p in enumerate(written):
+        np.testing.assert_array_equal(D.read_image_bgr(p), D.to_uint8(ref[i]))
+    b = open(str(tmp_path / "v.avi"), "rb").read()
+    assert struct.unpack("<I", b[48:52])[0] == 7                                      # avih.dwTotalFrames
+    # a frame of another size in the list is an error of the fast path, not silent garbage
+    D.write_image_bgr(str(src / "f03.png"), pkg.synth_frame(3, 16, 32, kind="smooth"))
+    with pytest.raises(ValueError):
+        D.stylize_files(_FramesModel(oracle, pkg.synthetic_weights(0)), str(tmp_path / "style.png"), D.list_frames(str(src / "*.png")),
+                        str(tmp_path / "out2"), chunk=4, io_threads=2, log=lambda *_: None)
+
+
+def _cli_rank(rank, world, port, argv):
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      RRV_DRIVER_BACKEND="gloo")
+    import torch
+    torch.set_num_threads(2)
+    import rerevst_oracle as O
+    pkg = importlib.import_module("rerevst-code_amd")
+    drv = importlib.import_module("rerevst-code_amd.driver")
+    rc = drv.main(argv, model_factory=lambda args, device: _FramesModel(O, pkg.synthetic_weights(0)))
+    assert rc == 0
+
+
+def test_cli_two_ranks_gloo_equals_single_process(tmp_path, pkg, oracle):
+    """`driver --gpus 2` control flow on CPU (gloo): rank 0 prepares, one state broadcast, contiguous shards, every rank
+    writes its own frames, rank 0 muxes the AVI from the files behind a barrier — same files as the single-process run."""
+    import torch.multiprocessing as mp
+    src, frames, style = _write_inputs(tmp_path, pkg, 5)
+    common = ["--style", str(tmp_path / "style.png"), "--frames", str(src / "*.png"), "--checkpoint", "synthetic", "--io-threads", "2", "--chunk", "2"]
+    port = 29900 + os.getpid() % 90
+    mp.spawn(_cli_rank, args=(2, port, common + ["--out", str(tmp_path / "o2"), "--gpus", "2", "--video", str(tmp_path / "v2.avi")]), nprocs=2, join=True)
+    rc = D.main(common + ["--out", str(tmp_path / "o1"), "--video", str(tmp_path / "v1.avi")],
+                model_factory=lambda args, device: _FramesModel(oracle, pkg.synthetic_weights(0)))
+    assert rc == 0
+    names = sorted(os.listdir(str(tmp_path / "o1")))
+    assert names == sorted(os.listdir(str(tmp_path / "o2"))) == ["f%02d.png" % i for i in range(5)]
+    for nm in names:
+        np.testing.assert_array_equal(D.read_image_bgr(str(tmp_path / "o2" / nm)), D.read_image_bgr(str(tmp_path / "o1" / nm)))
+    b1, b2 = open(str(tmp_path / "v1.avi"), "rb").read(), open(str(tmp_path / "v2.avi"), "rb").read()
+    assert struct.unpack("<I", b2[48:52])[0] == 5 and len(b1) == len(b2)             # the JPEGs of identical frames

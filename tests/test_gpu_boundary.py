@@ -339,7 +339,34 @@ def test_async_tickets_equal_plain_transfer(hip, pkg, oracle):
     np.testing.assert_array_equal(hip.result(t), ref[0])           # waiting twice is harmless
     with pytest.raises(pkg.RRVError) as e:                         # a ticket that was never issued
         hip.result((t[0] + 1000, t[1]))
-    assert e.value.code == -1
+    assert e.value.code == -1 and "no such ticket" in str(e.value)   # its own message, not a stale rrv_last_error
+
+
+def test_async_ticket_input_may_be_overwritten_and_ticket_dropped(hip, pkg, oracle):
+    """include/rerevst_hip.h: `frame_bgr` may be reused as soon as rrv_transfer_async returns — also a PAGE-LOCKED one,
+    which is the direct source of the asynchronous H2D copy (the next frame decoded into the same pinned
+    buffer corrupted the input).  And a ticket the caller drops keeps its output block until it is retired."""
+    import gc
+    frames = [oracle.reflect_pad(pkg.synth_frame(960 + i, 200, 264, kind="noise"), 384, 384) for i in range(6)]
+    ref = [hip.transfer(f) for f in frames]
+    buf = pkg.pinned_empty(frames[0].shape, np.uint8)              # ONE page-locked input buffer, refilled for every frame
+    tickets = []
+    for f in frames:
+        buf[...] = f
+        tickets.append(hip.transfer_async(buf))
+        buf[...] = 255 - f                                         # overwritten the moment the call returns
+    for k in range(6):
+        np.testing.assert_array_equal(hip.result(tickets[k]), ref[k])
+    # dropped tickets: the outputs stay referenced by the Stylization object while the GPU writes them
+    for rep in range(3):
+        for f in frames[:4]:
+            hip.transfer_async(f)                                   # ticket discarded at once
+        gc.collect()
+        junk = [pkg.pinned_empty(ref[0].shape, np.float32) for _ in range(2)]      # pool / allocator churn next to the open tickets
+        del junk
+    last = hip.transfer_async(frames[5])
+    np.testing.assert_array_equal(hip.result(last), ref[5])
+    hip.sync()
 
 
 def test_feature_cache_cap_falls_back_to_reencoding(pkg, weights, oracle):

@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""One-command parity check on a REAL checkpoint (the released `style_net-TIP-final.pth`, which the reference tree only
+links to: /root/reference/README.md:83-85 — it is a 0-byte placeholder there, so the committed goldens use seeded weights).
+
+    python tools/check_checkpoint.py /path/to/style_net-TIP-final.pth [--style img] [--frames f0.png f1.png ...]
+
+Runs the reference driver's flow (test/generate_real_video.py:95-171: prepare_style -> clean -> add(every 8th frame + the
+last, unpadded) -> compute -> transfer(frame padded by ReshapeTool) -> crop) twice with the checkpoint's weights — on the HIP
+library through the C ABI and on the CPU oracle (oracle/rerevst_oracle.py, the pinned restatement of the reference) — and
+prints the margin of every field against the stated tolerances (tests/state_bounds.py): the saved state per layer and
+field (mean / std / min / max / filters / style moments), the pre-clamp network output and the delivered image.
+Default inputs are the reference's own default inputs (inputs/plum_flower.jpg, inputs/ambush_4/*.png) as stored, PNG
+encoded, in tests/golden/real_default.npz.  Exit status 0 = every margin <= 1.0 (inside the bound), 1 = something is
+above its bound, 2 = could not run.  This is a checker (it imports the oracle); nothing of the product does.
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import state_bounds as T              # noqa: E402
+import rerevst_oracle as O            # noqa: E402  (checker only)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("checkpoint", help="reference state_dict (.pth, 107 keys) or an .npz with the same keys")
+    ap.add_argument("--style", help="style image (default: the reference's inputs/plum_flower.jpg from tests/golden/real_default.npz)")
+    ap.add_argument("--frames", nargs="+", help="frame files in order (default: the 33 ambush_4 frames' sampled subset of the golden)")
+    ap.add_argument("--transfer-index", type=int, default=-1, help="which frame to stylize (default: the golden's frame 12 / the middle frame)")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--oracle-backend", default="torch", choices=("torch", "numpy"), help="oracle convolutions: torch CPU conv2d (fast) or nine numpy GEMMs")
+    args = ap.parse_args()
+
+    pkg = importlib.import_module("rerevst-code_amd")
+    W = importlib.import_module("rerevst-code_amd.weights")
+    V = importlib.import_module("rerevst-code_amd.video")
+    try:
+        if args.checkpoint.endswith(".npz"):
+            weights = dict(np.load(args.checkpoint))
+        else:
+            weights = W.load_checkpoint(args.checkpoint)
+        missing = [k for k in W.weight_table() if k not in weights]
+        if missing:
+            print("checkpoint lacks %d of the %d keys the path needs, e.g. %s" % (len(missing), len(W.weight_table()), missing[:3]))
+            return 2
+    except Exception as e:
+        print("cannot read %s: %s: %s" % (args.checkpoint, type(e).__name__, e))
+        return 2
+
+    if args.frames:
+        from PIL import Image
+        rd = lambda f: np.ascontiguousarray(np.asarray(Image.open(f).convert("RGB"))[..., ::-1])      # BGR, as cv2.imread
+        frames = [rd(f) for f in args.frames]
+        sample = V.sample_indices(len(frames))
+        tid = args.transfer_index if args.transfer_index >= 0 else len(frames) // 2
+        style = rd(args.style) if args.style else None
+        frame_of = lambda i: frames[i]
+    else:
+        g = T.load_golden("real_default")
+        sample = [int(i) for i in g["sample_ids"]]
+        tid = args.transfer_index if args.transfer_index >= 0 else int(g["transfer_id"])
+        if ("frame%d_png" % tid) not in g.files:
+            print("the golden holds frames %s only" % sorted(int(k[5:-4]) for k in g.files if k.startswith("frame") and k.endswith("_png")))
+            return 2
+        frame_of = lambda i: T.decode_png(g["frame%d_png" % i])
+        style = None
+    if style is None:
+        style = T.decode_png(T.load_golden("real_default")["style_png"])
+
+    H, Wd = frame_of(tid).shape[:2]
+    PH, PW = O.padded_size(H), O.padded_size(Wd)
+    padded = O.reflect_pad(frame_of(tid), PH, PW)
+    print("checkpoint %s: %d tensors; style %dx%d, %d sampled frames of %dx%d, frame %d padded to %dx%d" %
+          (os.path.basename(args.checkpoint), len(weights), style.shape[0], style.shape[1], len(sample), H, Wd, tid, PH, PW), flush=True)
+
+    t0 = time.time()
+    try:
+        hip = pkg.Stylization(weights, cuda=True, device=args.device)
+    except Exception as e:
+        print("cannot create the HIP model: %s" % e)
+        return 2
+    hip.prepare_style(style); hip.clean()
+    for i in sample:
+        hip.add(frame_of(i))
+    hip.compute()
+    st_hip = hip.get_state()
+    out_hip = hip.transfer(padded)
+    pre_hip = hip.preclamp(PH, PW)
+    hip.close()
+    t_hip = time.time() - t0
+
+    t0 = time.time()
+    O.set_conv_backend(args.oracle_backend)
+    o = O.Stylization(weights)
+    o.prepare_style(style); o.clean()
+    for i in sample:
+        o.add(frame_of(i))
+    o.compute()
+    st_ref = o.get_state()
+    pre_ref, out_ref = o.transfer(padded, return_preclamp=True)
+    # the image and the pre-clamp output once more with the ORACLE's state injected into the HIP model: separates the
+    # per-frame path's error from what the (possibly ill-conditioned) statistics pass contributes
+    hip2 = pkg.Stylization(weights, cuda=True, device=args.device)
+    hip2.set_state(st_ref)
+    out_inj = hip2.transfer(padded)
+    pre_inj = hip2.preclamp(PH, PW)
+    hip2.close()
+    t_ref = time.time() - t0
+
+    crop = (slice(64, 64 + H), slice(64, 64 + Wd))
+    rows = T.state_fields(st_hip, st_ref)
+    print("\nsaved state (17 536 floats), worst entry per field, margin = |d| / (atol + 1e-4 |ref|):")
+    bad = 0
+    for name, ratio, k, gv, rv, _atol in rows:
+        flag = "" if ratio <= 1.0 else "   <-- ABOVE THE BOUND"
+        bad += ratio > 1.0
+        print("  %-26s %7.3f   [%4d] hip %+.6e  oracle %+.6e%s" % (name, ratio, k, gv, rv, flag))
+    sworst = max(r[1] for r in rows)
+
+    def img_margins(tag, pre, out):
+        pw, pmax = T.pre_worst(pre[crop], np.asarray(pre_ref)[crop])
+        im = float(np.abs(out[crop] - out_ref[crop]).max())
+        print("  %-46s pre-clamp margin %.3f (max|d| %.2e)   image max|d| %.4f grey levels (bound %.2f, margin %.3f)"
+              % (tag, pw, pmax, im, T.IMG_ATOL, im / T.IMG_ATOL))
+        return pw, im / T.IMG_ATOL
+    print("\nstylized frame (the window the driver keeps):")
+    p1, i1 = img_margins("HIP end to end (its own state):", pre_hip, out_hip)
+    p2, i2 = img_margins("HIP per-frame path, oracle state injected:", pre_inj, out_inj)
+    ok = sworst <= 1.0 and max(p1, i1, p2, i2) <= 1.0
+    print("\nHIP %.1f s, oracle (+ injected run) %.1f s.  worst margins: state %.3f, pre-clamp %.3f, image %.3f  ->  %s" %
+          (t_hip, t_ref, sworst, max(p1, p2), max(i1, i2), "PASS" if ok else "FAIL (%d state fields above the bound)" % bad))
+    if not ok and max(p2, i2) <= 1.0:
+        print("note: with the oracle's state injected the per-frame path is inside its bounds — the miss is in the statistics pass; "
+              "near-dead channels (rstd >> 1e3) make single state entries ill-conditioned in float32 (DESIGN.md §6).")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

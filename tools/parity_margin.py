@@ -64,6 +64,8 @@ for v in ("seed1", "dead", "dec4"):
     if v == "dec4":
         mine, _ = T.state_worst(st, g["state_fp64"]); theirs, _ = T.state_worst(g["state"], g["state_fp64"])
         extra = " | ill-conditioned: distance to the float64 reference state %.1fx the bound (the reference's own float32 run: %.1fx); image/pre-clamp below with the REFERENCE state" % (mine, theirs)
+        rows = {r[0]: r[1] for r in T.state_fields(st, g["state_fp64"])}; ref = {r[0]: r[1] for r in T.state_fields(g["state"], g["state_fp64"])}
+        extra += " | per field > 1 (HIP / reference float32, both vs float64): " + ", ".join("%s %.1f / %.1f" % (k, rows[k], ref[k]) for k in rows if rows[k] > 1 or ref[k] > 1)
         hip.set_state(g["state"])
     out = hip.transfer(O.reflect_pad(frames[tid], 192, 192)); pre = hip.preclamp(192, 192)
     report("global_a_" + v, st, g["state"], pre, g["pre"], out, g["out"], extra)
