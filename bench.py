@@ -54,6 +54,8 @@ def rocprof_name(kernel):
         return str(sum(EPI_BITS[t.strip()] for t in txt.split("|"))) if txt[:2] == "E_" else txt
     if base == "conv_wino":      # the row-split 8-wave kernel, <EPI, ABL>
         return "void conv_wino_split_k<%s, 0>(ConvP)" % epi(args)
+    if base == "conv_f43":       # F(4x4,3x3), <EPI>
+        return "void conv_f43_k<%s>(ConvP)" % epi(args)
     if base in ("conv_upw", "conv_upw_sc"):       # conv_wino_k<EPI, ABL, waves, UPS, SC>: rerevst_hip.hip UPW_NW
         return "void conv_wino_k<%s, 0, 4, 1, %d, 0>(ConvP)" % (epi(args), 1 if base.endswith("_sc") else 0)      # last: PERIMG
     if base == "conv_mfma":
@@ -173,7 +175,7 @@ def roofline_and_kernels(rows, nprof, frames_per_step, size, multistyle=0):
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     n, t_ms, fl, by, fx = dom[1]
     executed = fx / t_ms / 1e9
-    mf = [a for nm, a in agg.items() if nm.startswith(("conv_mfma", "conv_wino", "conv_upw"))]
+    mf = [a for nm, a in agg.items() if nm.startswith(("conv_mfma", "conv_wino", "conv_upw", "conv_f43"))]
     roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "frac_basis": "executed",
             "frac_executed": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
@@ -623,8 +625,8 @@ def main():
         # headline region: extras, never `value`.  Each is this script in a child process with its own steps / warm-up.
         if world == 1 and not args.no_extras and not args.no_other_configs and not NS and S == 512 and not args.pageable:
             model.close()
-            c2 = sub_leg(["--size", "256", "--steps", "8", "--warmup", "2"])
-            c5 = sub_leg(["--multistyle", "4", "--steps", "6", "--warmup", "2"])
+            c2 = sub_leg(["--size", "256", "--steps", "12", "--warmup", "3"])
+            c5 = sub_leg(["--multistyle", "4", "--steps", "16", "--warmup", "3"])
             out["config2"] = c2
             out["config5"] = c5
             out["config2_frames_per_s"] = c2.get("frames_per_s")

@@ -174,6 +174,16 @@ int rrv_release_features(rrv_handle h);
  * widens the grids of the small relu4_1-level layers; results are bit-identical for every setting.  Measured at
  * 1152 x 1152 x 4 styles: 340 / 339 / 330 frames/s for 1 / 2 / 4 (the two-stream pipeline already fills the chip). */
 int rrv_set_multistyle_group(rrv_handle h, int frames);
+
+/* Kernel choice for the same-resolution 3x3 layers of the per-frame path that have a Winograd F(4x4,3x3) pack (encoder
+ * conv1_2 .. conv3_4, ResidualBlock.conv2; test/style_network_global.py:271-281, :104): mode 0 = always F(2x2,3x3);
+ * 1 (default, also RRV_F43=) = F(4x4,3x3) where the launch has enough 32 x 32-pixel work items for it to win (from four
+ * 640 x 640 frames per launch, two 1152 x 1152 frames; 1.08-1.25x per layer) — a rule on the layer, the batch and the
+ * frame size only; 2 = always F(4x4,3x3).  The preparation pass (prepare_style / add / compute) and the frame mode always
+ * run F(2x2,3x3).  F(4x4,3x3) rounds 3-6x coarser than F(2x2,3x3) (both inside the stated parity bounds, profiles/
+ * r04_parity_margin.txt), so in mode 1 a frame's low-order bits depend on how many frames share its launch; with a
+ * fixed mode every entry delivers the same bits for the same frame, and every mode is run-to-run deterministic. */
+int rrv_set_f43(rrv_handle h, int mode);
 /* Capacity policy of the feature cache (default 64 GiB).  The reference spills every frame's feature to disk
  * (test.py:87-101, cache/%d.pt), so its video length is unbounded; here a cached feature costs 42 MB of HBM per
  * 1152x1152 frame.  Once the cache would exceed `bytes`, rrv_generate_content_features keeps the frame's uint8 pixels

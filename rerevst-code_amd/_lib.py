@@ -49,6 +49,7 @@ SYMBOLS = {
     "rrv_transfer_features_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     "rrv_release_features": (C.c_int, [C.c_void_p]),
     "rrv_set_multistyle_group": (C.c_int, [C.c_void_p, C.c_int]),
+    "rrv_set_f43": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_set_feature_cache_cap": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rrv_feature_cache_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "rrv_transfer_frame_mode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

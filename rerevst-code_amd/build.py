@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librerevst_hip.so")
 SOURCES = ["rerevst_hip.hip"]
-HEADERS = ["conv_mfma.h", "conv_wino.h", "conv_wino_split.h", "conv_thin.h", "prep_kernels.h", "../../include/rerevst_hip.h"]
+HEADERS = ["conv_mfma.h", "conv_wino.h", "conv_wino_split.h", "conv_f43.h", "conv_thin.h", "prep_kernels.h", "../../include/rerevst_hip.h"]
 
 
 def _stale():

@@ -1,12 +1,13 @@
-// tools/conv_f43.h — PROTOTYPE, not part of the library (DESIGN.md §4 "F(4x4,3x3): built, measured, not shipped"):
-// it wins 1.08-1.22x over the shipped F(2x2,3x3) kernel (profiles/r03_f43_bench.txt) and costs 3-6x the rounding error
-// — on the reference's default input it would put the pre-clamp error at 1.35x the stated bound (profiles/r03_f43_numerics.txt).
-//
-// Winograd F(4x4,3x3) 3x3 convolution on the fp32 matrix cores: 36 multiplies per 4x4 outputs instead of
+// conv_f43.h — Winograd F(4x4,3x3) 3x3 convolution on the fp32 matrix cores: 36 multiplies per 4x4 outputs instead of
 // 144 (the F(2x2,3x3) kernel of conv_wino_split.h needs 64), for the same-resolution 3x3 layers with Cin, Cout >= 64
-// (vgg19.features convs, test/style_network_global.py:271-281; ResidualBlock.conv2 :104,119-122).
+// (vgg19.features convs, test/style_network_global.py:271-281; ResidualBlock.conv2 :104,119-122) when a launch carries
+// enough frames to fill the chip with 32x32-pixel work items (rerevst_hip.hip: conv(), F43_MIN_BATCH).
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A,   6x6 patches four pixels apart, interpolation points 0, +-1, +-2, inf
+//
+// Exact in real arithmetic; in fp32 its rounding error is 3-6x that of F(2x2,3x3) (the transform matrices carry 4, 5, 8
+// and 1/24): measured against the reference goldens it leaves the pre-clamp output at <= 0.7 of the stated bound on the
+// layers it is used for (profiles/r04_parity_margin.txt), against 0.44 with F(2x2,3x3) everywhere.
 //
 // Why this form fits the machine where "36 positions x 32 couts x 16 channels" does not:
 //  * one wave per SIMD (4 waves, 512 registers each): a wave owns 16 tiles (8 x 32 output pixels) x 32 output channels
@@ -23,8 +24,19 @@
 //  raw : [halo row y 0..33][x & 3][x >> 2 (0..8)][32 B = 4 slots of one channel pair]; slot = pair ^ 2*((y>>2)&1):
 //        a read of patch piece (dy, dx) by the 16 tiles (2 x 8) x 2 pairs of a lane group covers 256 distinct bytes
 //  U   : [position 0..35][cout row 0..31][32 B]; slot = pair ^ 2*((row>>3)&1)
+//
+// F43_ABL (default 0; tools/f43_bench.hip builds one binary per value): microbenchmark switches — 1 no LDS-DMA after the
+// first stage, 2 no K-loop barriers, 4 no stores, 8 no input transform, 16 per-phase clock64 timeline into p.dbg, 32 no
+// epilogue.  The library is compiled with 0: every hook is a discarded constexpr branch.
 #pragma once
-#include "../rerevst-code_amd/csrc/conv_wino.h"
+#include "conv_wino.h"
+
+#ifndef F43_ABL
+#define F43_ABL 0
+#endif
+#ifndef F43_STAGGER
+#define F43_STAGGER 0      /* naps of 2048 clocks per chunk of an item and quarter phase (see "Phase stagger" in the kernel) */
+#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -151,23 +163,6 @@ __device__ __forceinline__ void f43_in6(LineFn&& L) {
         }, std::make_integer_sequence<int, 6>{});
     }, std::make_integer_sequence<int, 12>{});
 }
-// (superseded) MFMA-loop schedule of the next chunk's transform: iteration i, slot s (the gap behind the s-th MFMA) -> the 1-D
-// transform (columns dx = 0..5, then rows r = 0..5 as 6..11) and the ops [first, first + count) of it.
-// Column pass dx: iterations 4 + 2 dx and 5 + 2 dx, (2, 1, 2, 1) ops per slot; row pass r: iterations 16 + 3 r .. 18 + 3 r, one op per slot.
-struct F43Slot { int line, first, count; };
-constexpr F43Slot f43_slot(int i, int s) {
-    if (i >= 4 && i <= 15) {
-        const int dx = (i - 4) / 2, half = (i - 4) & 1;
-        const int first = half * 6 + (s == 0 ? 0 : s == 1 ? 2 : s == 2 ? 3 : 5);
-        return F43Slot{dx, first, (s & 1) ? 1 : 2};
-    }
-    if (i >= 16 && i <= 33) {
-        const int r = (i - 16) / 3, m = (i - 16) % 3;
-        return F43Slot{6 + r, 4 * m + s, 1};
-    }
-    return F43Slot{-1, 0, 0};
-}
-
 // 1-D output transform A^T (6 -> 4) on a channel pair:
 //   y0 = m0 + (m1 + m2) + (m3 + m4)     y1 = (m1 - m2) + 2 (m3 - m4)     y2 = (m1 + m2) + 4 (m3 + m4)     y3 = (m1 - m2) + 8 (m3 - m4) + m5
 __device__ __forceinline__ void f43_out(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
@@ -179,9 +174,12 @@ __device__ __forceinline__ void f43_out(const f32x2 m0, const f32x2 m1, const f3
     y3 = t2add<1>(t2fma4<1>(d2, t2fma4<1>(d2, d1)), m5);      // 8 is no inline constant: 4 d2 + (4 d2 + d1)
 }
 
-template <int EPI, int ABL = 0, int PK = 0>
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
+    static_assert(!(EPI & E_RES), "same-resolution residuals are not needed by the layers this kernel serves");
     using G = F43Geo;
+    constexpr int ABL = F43_ABL;      // microbenchmark switches; 0 in the library
+    constexpr int PK = 1;             // packed-fp32 input transform (one v_pk_* per op; measured 4-7 % faster than scalar pairs)
     constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, NT = G::NT, NPOS = G::NPOS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -410,6 +408,15 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         next_patch();
         __syncthreads();      // round-3 fix, as in the library kernels: raw(0) is read by every wave before the first chunk's LDS-DMA reuses its buffer
     }
+    // Phase stagger: every workgroup runs the same item stream (K loop without stores, then a 128 KB store burst), and
+    // workgroups that start together stay in lockstep — all 256 CUs then store at the same time at more than the HBM
+    // rate and every epilogue waits.  Workgroup w starts a quarter / half / three quarters of an item late (w / 8 mod 4:
+    // the XCD neighbours differ), once per launch.
+    if (F43_STAGGER && have) {
+        const int skew = (blockIdx.x >> 3) & 3;
+        const int naps = skew * nchunks * F43_STAGGER;        // x 64 x 32 clocks
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     if (ABL & 16) tl_t = clock64();
     while (have) {
         const int e_y0 = (cur.ty + p.ty0) * 32, e_x0 = (cur.tx + p.tx0) * 32, e_b = cur.b, e_ntile = cur.nt;
@@ -443,20 +450,40 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
             if (have) next_patch();
             continue;
         }
-        // ---- output transform Y = A^T M A (rows of M = acc[r*6 + k]) + fused epilogue, all in registers
+        // ---- output transform Y = A^T M A (rows of M = acc[r*6 + k]) + fused epilogue, all in registers.
+        // A lane ends with the 4 x 4 output pixels of its tile for 4 + 4 + 4 + 4 channels (two cout blocks x two channel pairs),
+        // so the 2 x 2 max pool (E_POOL: the tile holds four whole pooling windows) and the half-resolution residual
+        // (E_RES_UPS: the tile lies over 2 x 2 low-resolution pixels) stay inside the lane.
         const int yb = e_y0 + 8 * wave + 4 * tr, xb = e_x0 + 4 * tc;
         // Stores: wave-uniform 64-bit base (SGPRs: image, item origin, the wave's rows, pixel (i, j), cout block) + ONE
         // loop-invariant 32-bit lane offset (the tile inside the wave's 8 x 32 pixels and the lane's 4 couts): no
         // per-store address arithmetic in vector registers (precomputed addresses would be held across the whole K loop)
-        char* const sb = (char*)(p.out + (size_t)e_b * (size_t)(p.H + 2) * (p.W + 2) * p.Cout +
-                                 ((size_t)(e_y0 + 8 * wave + 1) * (p.W + 2) + e_x0 + 1) * p.Cout + e_ntile * 32);
-        const int rowb = (p.W + 2) * p.Cout * 4, pixb = p.Cout * 4;
+        constexpr bool POOL = (EPI & E_POOL) != 0;
+        const int Ho = POOL ? (p.H >> 1) : p.H, Wo = POOL ? (p.W >> 1) : p.W;
+        char* const sb = (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout +
+                                 ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2) + (POOL ? (e_x0 >> 1) : e_x0) + 1) * p.Cout + e_ntile * 32);
+        const int rowb = (Wo + 2) * p.Cout * 4, pixb = p.Cout * 4;
+        const unsigned st_off = POOL ? (unsigned)(((2 * tr) * (Wo + 2) + 2 * tc) * p.Cout + 4 * q) * 4u : lane_off;
         const bool interior = e_y0 + 32 <= p.H && e_x0 + 32 <= p.W;       // wave-uniform: no per-pixel masks inside the image
+        const float* res_b = nullptr;
+        if constexpr ((EPI & E_RES_UPS) != 0) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout + e_ntile * 32 + 4 * q;
         // Register diet: a 16-cout block is finished in two channel-pair halves — T (6 x 4 pairs) and the first half's 16
         // output pairs are all that is live besides the next item's V(0) — so nothing spills between the K loops.
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             const char* pl = par + (nb * 16 + 4 * q) * 4;
+            f32x4 rres[2][2];    // E_RES_UPS: the 2 x 2 low-resolution residual pixels under the tile (requested now, used ~3000 clocks later)
+            if constexpr ((EPI & E_RES_UPS) != 0) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        // pixels outside the image read the tensor's first pixel instead (valid memory; their outputs are never stored)
+                        const bool in = (yb + 2 * a < p.H) && (xb + 2 * b2 < p.W);
+                        const int pix = in ? (((yb >> 1) + a + 1) * (p.Wr + 2) + (xb >> 1) + b2 + 1) : 0;
+                        rres[a][b2] = *(const f32x4*)(res_b + (size_t)pix * p.Cout + nb * 16);
+                    }
+            }
             f32x2 Y0[4][4];      // [i][j]: channels 0, 1 of the lane's four
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -467,6 +494,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                     f43_out(PR(r * 6 + 0), PR(r * 6 + 1), PR(r * 6 + 2), PR(r * 6 + 3), PR(r * 6 + 4), PR(r * 6 + 5), T[r][0], T[r][1], T[r][2], T[r][3]);
                     __builtin_amdgcn_sched_barrier(0);      // accumulators are copied out of the AGPRs row by row, not all up front
                 }
+                f32x4 pool_prev[2];      // E_POOL: the even column's row-pair maxima, waiting for the odd column
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x2 Y[4];
@@ -477,15 +505,39 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                         continue;
                     }
                     const f32x4 bias = *(const f32x4*)(pl);
+                    f32x4 o4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         f32x4 o = e4add(f32x4{Y0[i][j][0], Y0[i][j][1], Y[i][0], Y[i][1]}, bias);
                         if (EPI & E_RELU) o = f4relu(o);
                         if (EPI & E_LRELU) o = f4lrelu(o);
                         if (EPI & E_NORM1) o = f4norm_clamp(o, *(const f32x4*)(pl + 128), *(const f32x4*)(pl + 256), *(const f32x4*)(pl + 384), *(const f32x4*)(pl + 512));
-                        char* const dst = sb + (i * rowb + j * pixb + nb * 64);
-                        if (ABL & 4) { if (o[0] == 123.456f) *(float*)(dst + lane_off) = o[0]; }
-                        else if (interior || (yb + i < p.H && xb + j < p.W)) *(f32x4*)(dst + lane_off) = o;
+                        if constexpr ((EPI & E_RES_UPS) != 0) o = e4add(o, rres[i >> 1][j >> 1]);
+                        if (EPI & E_NORM2)
+                            o = e4fma(f4norm_clamp(o, *(const f32x4*)(pl + 640), *(const f32x4*)(pl + 768), *(const f32x4*)(pl + 896), *(const f32x4*)(pl + 1024)),
+                                      *(const f32x4*)(pl + 1280), *(const f32x4*)(pl + 1152));
+                        o4[i] = o;
+                    }
+                    if constexpr (POOL) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            f32x4 m;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m[e] = fmaxf(o4[2 * a][e], o4[2 * a + 1][e]);
+                            if ((j & 1) == 0) { pool_prev[a] = m; continue; }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], pool_prev[a][e]);
+                            char* const dst = sb + (a * rowb + (j >> 1) * pixb + nb * 64);
+                            if (ABL & 4) { if (m[0] == 123.456f) *(float*)(dst + st_off) = m[0]; }
+                            else if (interior || ((yb >> 1) + a < Ho && (xb >> 1) + (j >> 1) < Wo)) *(f32x4*)(dst + st_off) = m;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            char* const dst = sb + (i * rowb + j * pixb + nb * 64);
+                            if (ABL & 4) { if (o4[i][0] == 123.456f) *(float*)(dst + st_off) = o4[i][0]; }
+                            else if (interior || (yb + i < p.H && xb + j < p.W)) *(f32x4*)(dst + st_off) = o4[i];
+                        }
                     }
                 }
             }

@@ -115,7 +115,7 @@ __device__ __forceinline__ void bufld16_rs(rsrc_t rs, char* lds_wave_base, int v
 #endif
 }
 
-// ABL is for tools/conv_microbench.hip only (ablations: 1 = no loads after the first stage,
+// ABL is for microbenchmarks only (round-1 ablations: 1 = no loads after the first stage,
 // 2 = no barriers, 4 = no stores); the library always instantiates ABL = 0.
 // MSUB overrides the number of M-subtiles per wave (tile rows = WAVES_M * MSUB * 2); LD selects the
 // LDS-DMA flavour (0: global_load_lds, 1: buffer_load ... lds with a wave-uniform descriptor).

@@ -2,7 +2,7 @@
 // both forms) and the kernel conv_wino_k = the UPSAMPLE-FUSED form (UPS = 1, 4 waves, two workgroups per CU:
 // ResidualBlock.conv1 behind the nearest-x2 upsample, test/style_network_global.py:100-103,116-118).  The F(2x2,3x3)
 // layers run on conv_wino_split.h, which reuses everything here.  (The general kernel this one was specialised from —
-// with the superseded 4-wave / channel-split F(2x2,3x3) forms — lives in tools/conv_wino_ab.h for the microbenchmarks.)
+// with the superseded 4-wave / channel-split F(2x2,3x3) forms — is in the git history up to round 3, tools/conv_wino_ab.h.)
 //
 // The 9-tap contraction becomes element-wise GEMMs over transform positions:
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A
@@ -182,7 +182,7 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
 // PERIMG = 1: per-image state (ConvP::par_bstride / bias_bstride / w_bstride), a separate instantiation as in conv_wino_split.h
 template <int EPI, int ABL = 0, int NW = 4, int UPS = 1, int SC = 0, int PERIMG = 0>
 __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_wino_k(const ConvP p) {
-    static_assert(UPS == 1 && NW == 4, "library kernel: upsample-fused form, 4 waves (other forms: tools/conv_wino_ab.h)");
+    static_assert(UPS == 1 && NW == 4, "library kernel: upsample-fused form, 4 waves");
     static_assert(!(EPI & E_POOL), "no pooling behind an upsample");
     using G = WinoGeo<NW, UPS, SC>;
     constexpr int NPU = G::NPU;

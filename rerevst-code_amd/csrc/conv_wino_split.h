@@ -20,6 +20,13 @@
 #pragma once
 #include "conv_wino.h"
 
+// WSPLIT_ABL (default 0; tools/wsplit_bench.hip builds one binary per value): microbenchmark switches of THIS kernel —
+// 1 no LDS-DMA after an item's first stage, 2 no K-loop barriers, 4 no stores, 32 no epilogue.  The library is compiled
+// with 0: every hook is a discarded constexpr branch (the instruction stream is unchanged, checked with hipcc -S).
+#ifndef WSPLIT_ABL
+#define WSPLIT_ABL 0
+#endif
+
 #define WSPLIT_XCH_BYTES 32768          /* exchange: 8 waves x 4 vectors x 64 lanes x 16 B */
 #define WSPLIT_SMEM_BYTES (WinoGeo<8, 0>::SMEM + WSPLIT_XCH_BYTES)   /* 146 KB */
 
@@ -42,7 +49,7 @@ struct WSplitSched {
 };
 
 // PERIMG = 1: per-image state (ConvP::par_bstride / bias_bstride / w_bstride; the grouped multi-style decoder).  A
-// separate instantiation: the extra scalar state costs the shared-state kernels ~1 % (tools/wsplit_ab2.hip).
+// separate instantiation: the extra scalar state costs the shared-state kernels ~1 % (profiles/r03_wsplit_ab2.txt).
 template <int EPI, int PERIMG = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     using G = WinoGeo<8, 0>;
@@ -204,8 +211,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                 asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(d[3 * (i - 2) + 0]), "+v"(d[3 * (i - 2) + 1]), "+v"(d[3 * (i - 2) + 2]), "+v"(u[i & 3][0]), "+v"(u[i & 3][1]) : "i"(S::younger(i)));
             else lds_release2<S::younger(i)>(u[i & 3][0], u[i & 3][1]);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i < G::U_IT) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
-            if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
+            if constexpr (!(WSPLIT_ABL & 1)) {
+                if constexpr (i < G::U_IT) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
+                if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
+            }
             const f32x4 vv = vcur[(i & 3) * 2 + (i >> 2)];
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -224,9 +233,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
     // (stores of the previous item may still be among the outstanding ones: then even fewer loads are, which is safe).
     constexpr int NRES = (EPI & E_RES_UPS) ? 2 : (EPI & E_RES) ? 4 : 0;
     auto barrier_first_chunk = [&]() {
+        if constexpr ((WSPLIT_ABL & 2) != 0) return;
         if constexpr (NRES) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NRES) : "memory");
         else __syncthreads();
     };
+    auto barrier_chunk = [&]() { if constexpr (!(WSPLIT_ABL & 2)) __syncthreads(); };
 
     // ---- persistent loop over (pixel tile, cout slab) work items; only the first item has a prologue (see conv_wino_k)
     int par_ntile = -1, par_img = -1;
@@ -295,14 +306,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
         chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, va, vb, res_hook);
         barrier_first_chunk();    // U(c+1), raw(c+2) landed and visible; buffers of chunk c free
         chunk_body(1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va, no_hook);
-        __syncthreads();
+        barrier_chunk();
         for (int c = 2; c < nchunks; c += 2) {
             chunk_body(c, std::integral_constant<int, 0>{}, std::false_type{}, va, vb, no_hook);
-            __syncthreads();
+            barrier_chunk();
             chunk_body(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, vb, va, no_hook);
-            __syncthreads();
+            barrier_chunk();
         }
         cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;
+        if constexpr ((WSPLIT_ABL & 32) != 0) {      // microbench only: no epilogue (the accumulators stay alive)
+            f32x4 sacc = acc[0][0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) if (i || nb) sacc += acc[i][nb];
+            if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 123.456f) p.out[tid] = sacc[0];
+            continue;
+        }
 
         // ---- output transform: row sums of the wave's two rows, partner's row through LDS, fused epilogue
         f32x4 T[2][2][2];                         // [rl][j][nb]: T'[r][j] = sum_k M[r][k] A[k][j]
@@ -371,7 +391,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                         }
                     }
                     const int y2 = yb >> 1, x2 = xb >> 1;
-                    if (y2 < Ho && x2 < Wo) *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
+                    if constexpr ((WSPLIT_ABL & 4) != 0) { if (pooled[0] == 123.456f) out_b[co] = pooled[0]; }
+                    else if (y2 < Ho && x2 < Wo) *(f32x4*)(out_b + ((y2 + 1) * (Wo + 2) + x2 + 1) * p.Cout + co) = pooled;
                 }
             } else {
                 const char* theirs = xch + (wave ^ 1) * 4096 + lane * 16;
@@ -383,7 +404,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
                     f32x4 o = finish(Y, bias, m1, r1, lo1, hi1);
                     if (EPI & (E_RES | E_RES_UPS)) o = e4add(o, resv[nb][j]);
                     if (EPI & E_NORM2) o = e4fma(f4norm_clamp(o, m2, r2, lo2, hi2), sstd, smean);
-                    if (y < p.H && x < p.W) *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
+                    if constexpr ((WSPLIT_ABL & 4) != 0) { if (o[0] == 123.456f) out_b[co] = o[0]; }
+                    else if (y < p.H && x < p.W) *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
                 }
             }
         }

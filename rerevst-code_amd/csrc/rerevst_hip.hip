@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <string.h>
+#include <cmath>
 #include <thread>
 #include <stdio.h>
 #include <map>
@@ -17,6 +18,7 @@
 #include "conv_mfma.h"
 #include "conv_wino.h"
 #include "conv_wino_split.h"
+#include "conv_f43.h"
 #include "conv_thin.h"
 #include "prep_kernels.h"
 
@@ -50,6 +52,8 @@ struct ConvW {           // one convolution's device weights
     float* pk_wino = nullptr; // Winograd F(2x2,3x3) transformed pack for conv_wino_k
     float* pk_ups = nullptr; // upsample-fused transform pack (9 positions) for conv_wino_k<.., UPS = 1> (convs behind a nearest-x2 upsample)
     float* pk_ups_sc = nullptr; // the same with the block's 1x1 shortcut as tenth position (conv_wino_k<.., UPS = 1, SC = 1>)
+    int f43_bit = 0;         // index of the layer in rrv_ctx::f43_layers (encoder conv1_2 .. conv3_4 = 0..6, slice4/3/2.conv2 = 7..9)
+    float* pk_f43 = nullptr; // Winograd F(4x4,3x3) transformed pack for conv_f43_k (encoder convs and ResidualBlock.conv2 of the per-frame path)
     float* bias = nullptr;   // [Cout] (zeros for bias-free convs)
     int Cout = 0, Cin = 0, taps = 0, BN = 0;
 };
@@ -90,6 +94,10 @@ struct StyleState {
 };
 
 }  // namespace
+
+// Layers that run F(4x4,3x3) where the launch geometry lets it win (use_f43): bit 0..6 = encoder conv1_2, conv2_1, conv2_2,
+// conv3_1, conv3_2, conv3_3, conv3_4; bit 7..9 = slice4 / slice3 / slice2 .conv2.
+constexpr unsigned F43_DEFAULT_LAYERS = 0x3ff;
 
 struct rrv_ctx {
     int dev = 0;
@@ -160,6 +168,9 @@ struct rrv_ctx {
     struct Ticket { long id = -1; float* out = nullptr; size_t out_bytes = 0; bool open = false; } tickets[4];
     long next_ticket = 0;
     int grid_share = 1;               // rrv_set_grid_share: persistent grids use 1/grid_share of the CUs
+    int f43_mode = 1;                 // rrv_set_f43 / RRV_F43: layers with an F(4x4,3x3) pack run on conv_f43_k — 0 never, 1 where the launch has enough work items for it to win (use_f43), 2 always
+    unsigned f43_layers = F43_DEFAULT_LAYERS;   // which of the packed layers may run on conv_f43_k (RRV_F43_LAYERS overrides: experiments / parity attribution)
+    bool f43_path = false;            // true inside transfer_device only: the preparation pass (prepare_style / add / compute, frame mode) always runs F(2x2,3x3)
     int ms_group = 1;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
     int host_io = 0;                  // rrv_set_host_io: 0 = staged H2D / D2H copies, 1 = zero copy (kernels read / write page-locked host memory), 2 = input only, 3 = output only
     int n_cus = 256;
@@ -390,6 +401,15 @@ hipError_t wsplit_attr() {
     if (e == hipSuccess && PERIMG) e = hipFuncSetAttribute((const void*)conv_wino_split_k<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES);
     return e;
 }
+template <int EPI>
+void f43_launch(const ConvP& p, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_f43_k<EPI>), grid, dim3(F43Geo::NT), F43Geo::SMEM, s, p);
+}
+template <int EPI>
+hipError_t f43_attr() { return hipFuncSetAttribute((const void*)conv_f43_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F43Geo::SMEM); }
+#define FK(EPI) {32, 9, 0, EPI, &f43_launch<EPI>, "conv_f43<" #EPI ">", &f43_attr<EPI>, nullptr}
+// F(4x4,3x3): the same-resolution 3x3 layers of the per-frame path with Cin, Cout >= 64, when the launch carries enough
+// frames (conv()).  3-6x the rounding error of F(2x2,3x3) and 1.13-1.22x its rate at 8 frames per launch.
 #define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI, 0>, "conv_wino<" #EPI ">", &wsplit_attr<EPI, 0>, nullptr}
 // decoder layers: also instantiated with per-image state (grouped multi-style launches)
 #define WKI(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI, 0>, "conv_wino<" #EPI ">", &wsplit_attr<EPI, 1>, &wsplit_launch<EPI, 1>}
@@ -409,13 +429,43 @@ const ConvKey WINO_TABLE[] = {
     UWS(E_LRELU),
 };
 
+const ConvKey F43_TABLE[] = { FK(E_RELU), FK(E_RELU | E_POOL), FK(E_RELU | E_NORM1), FK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2) };
+
+// Does this call run on conv_f43_k?  (Also asked by the callers that choose window alignments.)
+// Mode 1 decides per layer and launch geometry.  A conv_f43_k work item is 32 x 32 pixels x 32 couts, four times the
+// F(2x2,3x3) kernel's, so a launch has a quarter of the items and loses more to the last, partially filled round of the
+// 256 persistent workgroups; its rate on a long item stream is `base` times the F(2x2,3x3) kernel's (tools/f43_bench.hip
+// at eight 640 x 640 frames per launch with the round losses taken out, profiles/r04_f43_bench.txt).  F(4x4,3x3) runs where
+// base x (F(2x2) round loss) / (F(4x4) round loss) >= 1.04: from four 640 x 640 frames per launch everywhere, from two
+// 1152 x 1152 frames, from one where the items are long (256 channels).  The rule depends on the layer, the batch and
+// the frame size only (not on what else is in flight): the same call always makes the same choice.
+bool use_f43(rrv_handle h, const ConvW& w, int B, int H, int W, int epi, bool ups, int ksplit, bool per_image) {
+    if (!h->f43_path || !w.pk_f43 || !((h->f43_layers >> w.f43_bit) & 1u) || ups || ksplit > 1 || per_image || h->f43_mode == 0) return false;
+    if (h->f43_mode == 2) return true;
+    const double R = 256.0;      // persistent workgroups of a full-chip launch (MI355X: one per CU)
+    auto round_loss = [&](double items) { return std::ceil(items / R) / (items / R); };
+    const double slabs = w.Cout / 32;
+    const double items43 = (double)((H + 31) / 32) * ((W + 31) / 32) * B * slabs, items23 = (double)((H + 15) / 16) * ((W + 15) / 16) * B * slabs;
+    const int ci = w.Cin >= 256 ? 2 : (w.Cin >= 128 ? 1 : 0);
+    static const double BASE_POOL[3] = {1.25, 1.28, 1.35}, BASE_RELU[3] = {1.13, 1.22, 1.26}, BASE_RES[3] = {1.11, 1.19, 1.26};
+    const double base = (epi & E_POOL) ? BASE_POOL[ci] : (epi & E_RES_UPS) ? BASE_RES[ci] : BASE_RELU[ci];
+    return base * round_loss(items23) / round_loss(items43) >= 1.04;
+}
+
 int conv(rrv_handle h, const ConvCall& c) {
     const ConvW& w = *c.w;
     const ConvKey* k = nullptr;
     bool wino = false;
+    bool f43 = use_f43(h, w, c.B, c.H, c.W, c.epi, c.ups, c.ksplit, (c.par_bstride | c.bias_bstride) != 0 || c.w_bstride != 0) &&
+               !((c.wy0 | c.wx0 | c.wy1 | c.wx1) & 31);      // 32 x 32 pixel work items: a window must be aligned to them
+    if (f43) {
+        f43 = false;
+        for (const ConvKey& e : F43_TABLE)
+            if (e.EPI == c.epi) { k = &e; f43 = true; wino = true; break; }
+    }
     const bool fuse_sc = c.ups && c.sc_out != nullptr;
     if (fuse_sc && !w.pk_ups_sc) return fail(h, RRV_E_ARG, "conv: no shortcut-fused pack for this layer");
-    if (c.ups ? w.pk_ups != nullptr : w.pk_wino != nullptr) {      // every 3x3 layer with a transform-domain pack runs conv_wino_k
+    if (!f43 && (c.ups ? w.pk_ups != nullptr : w.pk_wino != nullptr)) {      // every 3x3 layer with a transform-domain pack runs conv_wino_k
         for (const ConvKey& e : WINO_TABLE)
             if (e.EPI == c.epi && e.UPS == (int)c.ups && (e.TAPS == 10) == fuse_sc) { k = &e; wino = true; break; }
     }
@@ -435,7 +485,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W; p.Cin = w.Cin;
     p.out = c.out->p; p.H = c.H; p.W = c.W; p.Cout = w.Cout; p.B = c.B;
     p.in_bstride0 = 1;
-    p.wpk = wino ? (c.ups ? (fuse_sc ? w.pk_ups_sc : w.pk_ups) : w.pk_wino) : w.pk; p.bias = w.bias;
+    p.wpk = f43 ? w.pk_f43 : wino ? (c.ups ? (fuse_sc ? w.pk_ups_sc : w.pk_ups) : w.pk_wino) : w.pk; p.bias = w.bias;
     if (fuse_sc) {
         if (c.sc_out->H != c.in->H || c.sc_out->W != c.in->W || c.sc_out->C != w.Cout) return fail(h, RRV_E_ARG, "conv: shortcut output geometry mismatch");
         p.sc_out = c.sc_out->p;
@@ -454,12 +504,13 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (c.in->H != eh || c.in->W != ew) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
     if (c.out->H != oh || c.out->W != ow) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
-    if (wino) { p.tiles_y = (c.H + 15) / 16; }
+    const int TS = f43 ? 32 : 16;                        // pixel tile edge of a work item
+    if (wino) { p.tiles_x = (c.W + TS - 1) / TS; p.tiles_y = (c.H + TS - 1) / TS; }
     double win_frac = 1.0;
     if (wino && c.wy1 > c.wy0 && c.wx1 > c.wx0) {      // output window (on-device crop: nothing outside it is ever read)
         if ((c.wy0 | c.wx0 | c.wy1 | c.wx1) & 15) return fail(h, RRV_E_ARG, "conv: window must be tile aligned");
-        p.ty0 = c.wy0 / 16; p.tx0 = c.wx0 / 16;
-        p.tiles_y = (c.wy1 - c.wy0) / 16; p.tiles_x = (c.wx1 - c.wx0) / 16;
+        p.ty0 = c.wy0 / TS; p.tx0 = c.wx0 / TS;
+        p.tiles_y = (c.wy1 - c.wy0) / TS; p.tiles_x = (c.wx1 - c.wx0) / TS;
         win_frac = ((double)(c.wy1 - c.wy0) * (c.wx1 - c.wx0)) / ((double)((c.H + 15) / 16 * 16) * ((c.W + 15) / 16 * 16));
     }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * c.B), (unsigned)(w.Cout / w.BN));
@@ -477,12 +528,12 @@ int conv(rrv_handle h, const ConvCall& c) {
     }
     const double px = (double)c.B * c.H * c.W * win_frac;
     // algorithmic FLOPs = the reference's direct convolution (taps multiply-adds per output);
-    // executed: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 outputs (4 per pixel), the upsample-fused form 9 (2.25 per pixel)
+    // executed: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 outputs (4 per pixel), F(4x4,3x3) 36 per 4x4 (2.25 per pixel), the upsample-fused form 9 (2.25 per pixel)
     // (a fused shortcut adds its own 1x1 conv at the input resolution: one more GEMM position, 2.5 per output pixel)
     const double cin = w.Cin;
     const double flops_sc = fuse_sc ? 2.0 * c.B * c.in->H * c.in->W * (double)w.Cout * cin : 0.0;
     const double flops = 2.0 * px * w.Cout * cin * w.taps + flops_sc;
-    const double flops_exec = 2.0 * px * w.Cout * cin * (wino ? (c.ups ? (fuse_sc ? 2.5 : 2.25) : 4.0) : (double)w.taps);
+    const double flops_exec = 2.0 * px * w.Cout * cin * (f43 ? 2.25 : wino ? (c.ups ? (fuse_sc ? 2.5 : 2.25) : 4.0) : (double)w.taps);
     const double bytes = 4.0 * ((double)c.B * c.in->H * c.in->W * cin + (double)c.B * oh * ow * w.Cout +
                                 (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * cin * w.taps +
                                 (fuse_sc ? (double)c.B * c.in->H * c.in->W * w.Cout + (double)w.Cout * cin : 0.0));
@@ -525,6 +576,14 @@ int pack_wino(rrv_handle h, ConvW& w) {
     const size_t total = (size_t)w.Cout * w.Cin * 16;
     if (!w.pk_wino) RCHK(dalloc(h, &w.pk_wino, total, false));
     hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_wino, w.Cout, w.Cin, 0);
+    HIPCHK(hipGetLastError());
+    return RRV_OK;
+}
+
+int pack_f43(rrv_handle h, ConvW& w) {
+    const size_t total = (size_t)w.Cout * w.Cin * 36;
+    if (!w.pk_f43) RCHK(dalloc(h, &w.pk_f43, total, false));
+    hipLaunchKernelGGL(pack_f43_k, dim3(4096), dim3(256), 0, h->stream, (const float*)w.raw, w.pk_f43, w.Cout, w.Cin);
     HIPCHK(hipGetLastError());
     return RRV_OK;
 }
@@ -856,8 +915,9 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     const int slot = h->slot_override >= 0 ? h->slot_override : (h->n_slots > 1 && !h->profiling) ? h->next_slot : 0;
     h->next_slot = (slot + 1) % h->n_slots;
     h->last_slot = slot;
-    struct StreamScope { rrv_handle h; ~StreamScope() { h->stream = h->streams[0]; } } scope{h};
+    struct StreamScope { rrv_handle h; ~StreamScope() { h->stream = h->streams[0]; h->f43_path = false; } } scope{h};
     h->stream = h->streams[slot];
+    h->f43_path = true;            // the per-frame path: layers with an F(4x4,3x3) pack may run on conv_f43_k (use_f43)
     if (h->caller_sync) {    // stream-ordered against the caller: work queued on its stream so far precedes ours
         HIPCHK(hipEventRecord(h->slot_ev[slot], h->caller_stream));
         HIPCHK(hipStreamWaitEvent(h->stream, h->slot_ev[slot], 0));
@@ -909,6 +969,12 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         const Win crop{pc->top, pc->left, pc->top + pc->src_H, pc->left + pc->src_W};
         wl = grow(crop, 0);        // conv_last output tiles
         wo = grow(crop, 1);        // slice2.conv2 output feeding them
+        if (use_f43(h, h->conv["Decoder.slice2.conv2"], B, Ho, Wo, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2, false, 0, h->state_images != 0)) {      // 32 x 32 pixel work items: round the window out to them
+            const int lh = (Ho + 31) & ~31, lw = (Wo + 31) & ~31;
+            wo = Win{wo.y0 & ~31, wo.x0 & ~31, (wo.y1 + 31) & ~31, (wo.x1 + 31) & ~31};
+            if (wo.y1 > lh) wo.y1 = lh;
+            if (wo.x1 > lw) wo.x1 = lw;
+        }
         wa = grow(wo, 1);          // slice2.conv1 output (and, halved, the shortcut) feeding that
     }
     RCHK(resblock_frame(h, B, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr));
@@ -1312,6 +1378,8 @@ int rrv_create(int device, rrv_handle* out) {
     // the dynamic-LDS opt-in is a per-device function attribute: set it for THIS device, whatever other handles did
     for (const ConvKey& e : WINO_TABLE)
         if (ok && e.attr) ok = e.attr() == hipSuccess;
+    for (const ConvKey& e : F43_TABLE)
+        if (ok && e.attr) ok = e.attr() == hipSuccess;
     if (!ok) {
         delete h;
         return RRV_E_HIP;
@@ -1320,6 +1388,8 @@ int rrv_create(int device, rrv_handle* out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
     }
+    if (const char* e = getenv("RRV_F43_LAYERS")) h->f43_layers = (unsigned)strtoul(e, nullptr, 0);
+    if (const char* e = getenv("RRV_F43")) h->f43_mode = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("RRV_DEBUG")) h->debug = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     *out = h;
     return RRV_OK;
@@ -1463,6 +1533,9 @@ int rrv_finalize_weights(rrv_handle h) {
                 (void)hipFree(raw);
             } else {
                 RCHK(make_conv(h, k, VGG_COUT[i], VGG_CIN[i], 9, true));
+                // per-frame encoder, conv1_2 .. conv3_4 (conv4_1 = 256 -> 512 stays on F(2x2,3x3): alone it costs more of the
+                // parity margin than the other ten layers together, profiles/r03_f43_numerics.txt, for 3.5 % of the frame)
+                if (which == 0 && i < 8) { h->conv[k].f43_bit = i - 1; RCHK(pack_f43(h, h->conv[k])); }
             }
         }
     }
@@ -1473,6 +1546,8 @@ int rrv_finalize_weights(rrv_handle h) {
         RCHK(make_conv(h, p + ".conv1", bc[b][1], bc[b][0], 9, true, false));
         RCHK(pack_ups(h, h->conv[p + ".conv1"]));
         RCHK(make_conv(h, p + ".conv2", bc[b][1], bc[b][1], 9, true));
+        h->conv[p + ".conv2"].f43_bit = 7 + b;
+        RCHK(pack_f43(h, h->conv[p + ".conv2"]));
         RCHK(make_conv(h, p + ".conv_shortcut", bc[b][1], bc[b][0], 1, false));
         RCHK(pack_ups_sc(h, h->conv[p + ".conv1"], h->conv[p + ".conv_shortcut"]));
     }
@@ -2357,6 +2432,13 @@ int rrv_set_pipeline(rrv_handle h, int n_slots) {
 int rrv_set_grid_share(rrv_handle h, int share) {
     if (!h || share < 1 || share > 4) return RRV_E_ARG;
     h->grid_share = share;
+    return RRV_OK;
+}
+
+int rrv_set_f43(rrv_handle h, int mode) {
+    if (!h || mode < 0 || mode > 2) return RRV_E_ARG;
+    RCHK(sync_all(h));
+    h->f43_mode = mode;
     return RRV_OK;
 }
 

@@ -310,6 +310,11 @@ class Stylization():
         they wait for what is queued on it and it waits for their output — no host synchronisation needed."""
         self._chk(self._lib.rrv_set_caller_stream(self._h, C.c_void_p(stream_ptr), 1 if enable else 0))
 
+    def set_f43(self, mode):
+        """Kernel choice for the layers with a Winograd F(4x4,3x3) pack: 0 never, 1 (default) launches of >= 4 frames,
+        2 always (rrv_set_f43)."""
+        self._chk(self._lib.rrv_set_f43(self._h, int(mode)))
+
     def set_grid_share(self, share):
         """Persistent grids use 1/share of the CUs (share 1..4): launches of several streams run side by side."""
         self._chk(self._lib.rrv_set_grid_share(self._h, int(share)))

@@ -15,6 +15,13 @@ from state_bounds import (PRE_ATOL, PRE_RTOL, IMG_ATOL, STATE_RTOL, STATE_ATOL, 
                           pre_worst, assert_state_close_conditioned, assert_state_close_two_refs)
 
 
+# The suite's cross-entry invariants (batched == one frame per call == tickets == ..., bit for bit) hold for a FIXED kernel
+# choice; the library's default picks F(4x4,3x3) by the number of frames per launch (rrv_set_f43).  Everything but
+# tests/test_gpu_f43.py therefore runs with F(2x2,3x3) pinned; RRV_F43=2 in the environment runs the whole suite on the
+# F(4x4,3x3) kernels instead (profiles/r04_gpu_suite_f43_mode2.txt).
+os.environ.setdefault("RRV_F43", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

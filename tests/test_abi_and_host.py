@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "rerevst_hip.h")).read()
-    return sorted(set(re.findall(r"\b(rrv_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(rrv_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -216,3 +216,24 @@ def test_bench_roofline_fields_from_event_rows():
     assert k["conv_wino<E_RELU>"]["bound"] == "mfma" and abs(k["conv_wino<E_RELU>"]["frac_of_mfma_peak"] - 88.0 / 157.3) < 1e-3
     assert abs(k["conv_last"]["ms_per_frame"] - 8 * 0.25 / 64) < 1e-4
     assert b.roofline_and_kernels([], 0, 64, 512)[0] is None
+
+
+def test_tools_hold_no_copies_of_the_library_kernels():
+    """microbenchmarks are built from the library headers (ablation hooks behind WSPLIT_ABL / F43_ABL, empty
+    in the product build), never from hand-kept copies of a kernel that drift from it."""
+    tools = os.path.join(ROOT, "tools")
+    lib_kernels = set()
+    for f in os.listdir(os.path.join(ROOT, "rerevst-code_amd", "csrc")):
+        lib_kernels |= set(re.findall(r"__global__.*?\bvoid\s+(\w+)\s*\(", open(os.path.join(ROOT, "rerevst-code_amd", "csrc", f)).read()))
+    assert {"conv_wino_split_k", "conv_f43_k", "conv_wino_k"} <= lib_kernels
+    for f in os.listdir(tools):
+        if not f.endswith((".h", ".hip")):
+            continue
+        src = open(os.path.join(tools, f)).read()
+        defined = set(re.findall(r"__global__.*?\bvoid\s+(\w+)\s*\(", src))
+        assert not (defined & lib_kernels), "%s defines its own %s" % (f, sorted(defined & lib_kernels))
+        assert not re.search(r"conv_wino\w*_ab", src), "%s refers to a kernel copy" % f
+    # the hooks are compiled out of the product: the library build defines neither macro
+    b = importlib.import_module("rerevst-code_amd.build")
+    import inspect
+    assert "WSPLIT_ABL" not in inspect.getsource(b) and "F43_ABL" not in inspect.getsource(b)

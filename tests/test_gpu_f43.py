@@ -1,0 +1,166 @@
+"""GPU tests (-m gpu) of the F(4x4,3x3) kernel choice (conv_f43_k; rrv_set_f43, include/rerevst_hip.h): the library's
+default runs the same-resolution 3x3 layers of the per-frame path in F(4x4,3x3) when a launch carries >= 4 frames.
+The rest of the GPU suite pins RRV_F43=0 (tests/conftest.py) — its cross-entry bit-identity invariants hold for a
+FIXED kernel choice — so this module is where the default choice (mode 1) and the F(4x4,3x3) kernels themselves
+(mode 2: every launch) meet the reference goldens, the oracle, partial tiles, the crop windows and the debug mode."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_inputs, decode_png, assert_pre_close, pre_worst, IMG_ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(pkg, weights):
+    s = pkg.Stylization(weights, cuda=True)
+    s.set_state(load_golden("global_a")["state"])
+    yield s
+    s.close()
+
+
+def _batched(hip, padded, n=4):
+    out = hip.transfer_batch([padded] * n)
+    pre = hip.preclamp(*padded.shape[:2])
+    for k in range(1, n):
+        np.testing.assert_array_equal(out[k], out[0])         # a frame's arithmetic does not depend on its place in the launch
+    return np.array(out[0]), pre
+
+
+def test_f43_meets_the_reference_goldens(pkg, weights, oracle):
+    """conv_f43_k on every layer that has an F(4x4,3x3) pack (mode 2 for the small fixtures, whose launches the default
+    rule leaves to F(2x2,3x3); the default mode 1 for the reference's own 436 x 1024 frames at four per launch): reference
+    goldens at the stated bounds, through the batched host entry the bench times.  Margins: tools/parity_margin.py
+    (profiles/r04_parity_margin.txt)."""
+    s = pkg.Stylization(weights, cuda=True)
+    s.set_f43(2)
+    g = load_golden("global_a")
+    style, frames, ids, tid = golden_inputs(pkg, g)
+    s.set_state(g["state"])
+    out, pre = _batched(s, oracle.reflect_pad(frames[tid], 192, 192))
+    assert_pre_close(pre, g["pre"])
+    assert np.abs(out - g["out"]).max() <= IMG_ATOL
+    s.set_f43(0)
+    ref = s.transfer(oracle.reflect_pad(frames[tid], 192, 192))
+    assert not np.array_equal(ref, out)                          # the other kernels really ran
+    s.set_f43(1)
+    np.testing.assert_array_equal(_batched(s, oracle.reflect_pad(frames[tid], 192, 192))[0], ref)     # default rule: too few work items at 192 x 192 x 4
+    g = load_golden("real_default")                               # the reference's default invocation: 436 x 1024 in 576 x 1152
+    s.set_state(g["state"])
+    frame = decode_png(g["frame%d_png" % int(g["transfer_id"])])
+    padded = oracle.reflect_pad(frame, 576, 1152)
+    out, pre = _batched(s, padded)                                # mode 1, four frames per launch
+    s.set_f43(2)
+    np.testing.assert_array_equal(s.transfer(padded), out)        # = conv_f43_k on every packed layer
+    s.set_f43(1)
+    out, pre = out[64:500, 64:1088], pre[64:500, 64:1088]
+    assert_pre_close(pre[::4, ::4], g["pre_grid"])
+    assert_pre_close(pre[186:250, 480:544], g["pre_patch"])
+    assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
+    assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
+    # the on-device pad / crop entry (32-pixel-aligned windows for conv_f43_k) delivers the same pixels
+    crop = s.transfer_frames([frame] * 4)
+    for k in range(4):
+        np.testing.assert_array_equal(crop[k], out)
+    s.set_f43(2)
+    g = load_golden("img1_256")                                   # BASELINE config 1
+    s.set_state(g["state"])
+    frame = decode_png(g["frame_png"])
+    out, pre = _batched(s, oracle.reflect_pad(frame, 384, 384))
+    assert_pre_close(pre[64:320, 64:320][::2, ::2], g["pre_grid"])
+    assert np.abs(out[64:320, 64:320][::2, ::2] - g["out_grid"]).max() <= IMG_ATOL
+    s.close()
+
+
+def test_preparation_pass_never_uses_f43(pkg, weights, oracle):
+    """prepare_style / add / compute run F(2x2,3x3) whatever the mode: the saved state is bit-identical in modes 0 and 2."""
+    g = load_golden("global_a")
+    style, frames, ids, tid = golden_inputs(pkg, g)
+    states = []
+    for mode in (0, 2):
+        s = pkg.Stylization(weights, cuda=True)
+        s.set_f43(mode)
+        s.prepare_style(style); s.clean()
+        for i in list(ids) * 3:                                  # nine sampled frames: the deferred encoder launches carry eight
+            s.add(frames[i])
+        s.compute()
+        states.append(s.get_state())
+        s.close()
+    np.testing.assert_array_equal(states[0], states[1])
+
+
+def test_fixed_choice_is_bit_identical_across_entries(hip, pkg, oracle):
+    """Mode 2 (conv_f43_k in every launch): one frame per call == batched == tickets == pad/crop entry, bit for bit."""
+    hip.set_f43(2)
+    try:
+        PH, PW = oracle.padded_size(72), oracle.padded_size(100)    # ReshapeTool: 256 x 256 — what transfer_frames pads to on the device
+        frames = [oracle.reflect_pad(pkg.synth_frame(300 + i, 72, 100, kind="noise"), PH, PW) for i in range(9)]
+        one = [hip.transfer(f) for f in frames]
+        batch = hip.transfer_batch(frames)
+        for k in range(9):
+            np.testing.assert_array_equal(batch[k], one[k])
+        tickets = [hip.transfer_async(f) for f in frames[:4]]
+        for k in (2, 0, 3, 1):
+            np.testing.assert_array_equal(hip.result(tickets[k]), one[k])
+        raw = [pkg.synth_frame(300 + i, 72, 100, kind="noise") for i in range(5)]
+        crop = hip.transfer_frames(raw)
+        for k in range(5):
+            np.testing.assert_array_equal(crop[k], one[k][64:136, 64:164])
+        raw2 = [pkg.synth_frame(320 + i, 200, 168, kind="smooth") for i in range(4)]       # padded 384 x 320: crop windows cut 32 x 32 items
+        P2 = (oracle.padded_size(200), oracle.padded_size(168))
+        crop2 = hip.transfer_frames(raw2)
+        for k in range(4):
+            np.testing.assert_array_equal(crop2[k], hip.transfer(oracle.reflect_pad(raw2[k], *P2))[64:264, 64:232])
+        for rep in range(5):                                       # run-to-run determinism over both streams
+            again = hip.transfer_batch(frames)
+            np.testing.assert_array_equal(again, batch)
+    finally:
+        hip.set_f43(0)
+
+
+@pytest.mark.parametrize("hw", [(200, 136), (77, 90), (40, 56), (33, 31), (8, 8), (264, 40)])
+def test_f43_partial_tiles_vs_oracle(hw, pkg, oracle, weights):
+    """Frame sizes that leave partial 32 x 32 work items, partial 4 x 4 tiles and odd pooling sizes at every level, every
+    conv_f43_k epilogue (ReLU, ReLU + pool, LeakyReLU + norm + half-resolution residual + AdaIN): against the oracle."""
+    H, W = hw
+    style = pkg.synth_style(48, 40, kind="smooth", seed=11)
+    frames = [pkg.synth_frame(40 + i, H, W, kind="smooth") for i in range(3)]
+    o = oracle.Stylization(weights)
+    o.prepare_style(style); o.clean()
+    for f in frames[:2]:
+        o.add(f)
+    o.compute()
+    s = pkg.Stylization(weights, cuda=True)
+    s.set_f43(2)
+    s.set_state(o.get_state())
+    got = s.transfer(frames[2])
+    y = o.transfer(frames[2], return_preclamp=True)
+    ref = oracle.tensor_to_image(y)
+    assert got.shape == ref.shape == (H // 8 * 8, W // 8 * 8, 3)
+    assert np.abs(got - ref).max() <= IMG_ATOL
+    worst, _ = pre_worst(s.preclamp(*got.shape[:2]), y[0])
+    assert worst <= 1.0
+    b = s.transfer_batch([frames[2], frames[0], frames[2], frames[1], frames[2]])
+    np.testing.assert_array_equal(b[0], got); np.testing.assert_array_equal(b[2], got); np.testing.assert_array_equal(b[4], got)
+    s.close()
+
+
+def test_f43_under_the_bounds_checked_debug_mode(pkg, weights, oracle):
+    """Every conv_f43_k launch verified (guard bands, zero ring, slack rows): same bits as the unchecked run."""
+    s = pkg.Stylization(weights, cuda=True)
+    s.set_state(load_golden("global_a")["state"])
+    s.set_f43(2)
+    frames = [oracle.reflect_pad(pkg.synth_frame(700 + i, 50, 75, kind="noise"), 192, 208) for i in range(4)]
+    raw = [pkg.synth_frame(700 + i, 50, 75, kind="noise") for i in range(4)]
+    ref, ref_crop = np.array(s.transfer_batch(frames)), np.array(s.transfer_frames(raw))
+    s.set_debug(2)
+    np.testing.assert_array_equal(s.transfer_batch(frames), ref)
+    np.testing.assert_array_equal(s.transfer_frames(raw), ref_crop)
+    np.testing.assert_array_equal(s.transfer(frames[1]), ref[1])
+    s.set_debug(0)
+    s.close()
+
+
+def test_f43_mode_argument_is_checked(hip, pkg):
+    with pytest.raises(pkg.RRVError):
+        hip.set_f43(3)

@@ -103,7 +103,8 @@ def main():
         o.add(frame_of(i))
     o.compute()
     st_ref = o.get_state()
-    pre_ref, out_ref = o.transfer(padded, return_preclamp=True)
+    y_ref = o.transfer(padded, return_preclamp=True)              # [1][PH][PW][3] pre-clamp network output
+    pre_ref, out_ref = y_ref[0], O.tensor_to_image(y_ref)
     # the image and the pre-clamp output once more with the ORACLE's state injected into the HIP model: separates the
     # per-frame path's error from what the (possibly ill-conditioned) statistics pass contributes
     hip2 = pkg.Stylization(weights, cuda=True, device=args.device)

@@ -25,7 +25,14 @@ subsets = {
     "decoder conv2 at 64 and 128 channels": {11, 13},
     "encoder 64->64, 128->128 + decoder conv2 x3": {0, 2, 9, 11, 13},
     "whole encoder": {0, 1, 2, 3, 4, 5, 6, 7},
+    # round 4: candidate sets for the shipped kernel choice
+    "every same-resolution layer except conv4_1 (256->512)": {0, 1, 2, 3, 4, 5, 6, 9, 11, 13},
+    "every same-resolution layer except conv4_1 and the 64-channel ones": {1, 2, 3, 4, 5, 6, 9, 11},
+    "128/256-channel layers of the encoder (conv2_1..conv3_4) + s4/s3 conv2": {1, 2, 3, 4, 5, 6, 9, 11},
 }
+import os
+if os.environ.get("F43_ONLY"):
+    subsets = {k: v for k, v in subsets.items() if os.environ["F43_ONLY"] in k}
 for nm, use in subsets.items():
     state["i"] = 0; state["use"] = use
     pre = o.transfer(padded, return_preclamp=True)[0][64:500, 64:1088]

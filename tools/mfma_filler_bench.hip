@@ -1,5 +1,5 @@
 // tools/mfma_filler_bench.hip — what one extra instruction costs beside v_mfma_f32_16x16x4_f32 with ONE wave per SIMD.
-// The F(4x4,3x3) prototype (tools/conv_f43.h) runs one 512-register wave per SIMD; its K loop interleaves, per MFMA, about one
+// The F(4x4,3x3) kernel (rerevst-code_amd/csrc/conv_f43.h) runs one 512-register wave per SIMD; its K loop interleaves, per MFMA, about one
 // packed VALU op of the input transform, 0.75 ds_read_b64 and 0.13 LDS-DMA instructions.  This bench issues a stream of
 // independent MFMAs (8 accumulators round-robin) with N fillers of one kind between consecutive MFMAs and reports the
 // cycles per MFMA slot, i.e. how much of a filler hides in the 32-cycle shadow of the f32 MFMA.

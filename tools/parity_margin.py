@@ -18,13 +18,29 @@ for case in ("global_a", "global_b"):
     sworst, swhere = T.state_worst(st, g["state"])
     H, W = frames[0].shape[:2]
     PH, PW = O.padded_size(H), O.padded_size(W)
-    out = hip.transfer(O.reflect_pad(frames[tid], PH, PW)); pre = hip.preclamp(PH, PW)
-    if "pre" in g.files: rp, ro, p, o = g["pre"], g["out"], pre, out
-    else: rp, ro, p, o = g["pre_crop"], g["out_crop"], pre[64:64 + H, 64:64 + W], out[64:64 + H, 64:64 + W]
-    ep = np.abs(p - rp); bp = T.PRE_ATOL + T.PRE_RTOL * np.abs(rp)
-    print("%s: state worst entry at %.0f%% of its bound (%s) | pre-clamp max|d| %.2e (worst err/bound %.3f, ref std %.3f) | image max|d| %.4f grey levels (bound %.2f)"
-          % (case, 100 * sworst, swhere, ep.max(), (ep / bp).max(), rp.std(), np.abs(o - ro).max(), T.IMG_ATOL))
+    for mode in (0, 2):      # 0: F(2x2,3x3) everywhere; 2: F(4x4,3x3) on every layer that has a pack (what the default rule picks for launches with enough work items)
+        hip.set_f43(mode)
+        padded = O.reflect_pad(frames[tid], PH, PW)
+        out = hip.transfer_batch([padded] * 4)[0] if mode else hip.transfer(padded)
+        pre = hip.preclamp(PH, PW)
+        if "pre" in g.files: rp, ro, p, o = g["pre"], g["out"], pre, out
+        else: rp, ro, p, o = g["pre_crop"], g["out_crop"], pre[64:64 + H, 64:64 + W], out[64:64 + H, 64:64 + W]
+        ep = np.abs(p - rp); bp = T.PRE_ATOL + T.PRE_RTOL * np.abs(rp)
+        print("%s%s: state worst entry at %.0f%% of its bound (%s) | pre-clamp max|d| %.2e (worst err/bound %.3f, ref std %.3f) | image max|d| %.4f grey levels (bound %.2f)"
+              % (case, " [F(4x4,3x3)]" if mode else "", 100 * sworst, swhere, ep.max(), (ep / bp).max(), rp.std(), np.abs(o - ro).max(), T.IMG_ATOL))
+    hip.set_f43(0)
 hip.close()
+
+
+def both(hip, padded):
+    """[(tag, out, pre)] with F(2x2,3x3) everywhere and with F(4x4,3x3) on every layer that has a pack (mode 2)."""
+    res = []
+    for mode, tag in ((0, ""), (2, " [F(4x4,3x3)]")):
+        hip.set_f43(mode)
+        out = np.array(hip.transfer_batch([padded] * 4)[0]) if mode else hip.transfer(padded)
+        res.append((tag, out, hip.preclamp(*padded.shape[:2])))
+    hip.set_f43(0)
+    return res
 
 
 def report(case, got_state, ref_state, pre, ref_pre, out, ref_out, extra=""):
@@ -40,16 +56,16 @@ hip = pkg.Stylization(pkg.synthetic_weights(0), cuda=True)
 hip.prepare_style(T.decode_png(g["style_png"])); hip.clean()
 for i in g["sample_ids"]: hip.add(T.decode_png(g["frame%d_png" % int(i)]))
 hip.compute()
-out = hip.transfer(O.reflect_pad(T.decode_png(g["frame%d_png" % int(g["transfer_id"])]), 576, 1152))[64:500, 64:1088]
-pre = hip.preclamp(576, 1152)[64:500, 64:1088]
-report("real_default (plum_flower 400x564, ambush_4 436x1024, B=5)", hip.get_state(), g["state"], pre[::4, ::4], g["pre_grid"], out[::4, ::4], g["out_grid"],
-       " | dense 64x64 patch: pre %.2e, image %.4f" % (np.abs(pre[186:250, 480:544] - g["pre_patch"]).max(), np.abs(out[186:250, 480:544] - g["out_patch"]).max()))
+for tag, out, pre in both(hip, O.reflect_pad(T.decode_png(g["frame%d_png" % int(g["transfer_id"])]), 576, 1152)):
+    out, pre = out[64:500, 64:1088], pre[64:500, 64:1088]
+    report("real_default (plum_flower 400x564, ambush_4 436x1024, B=5)" + tag, hip.get_state(), g["state"], pre[::4, ::4], g["pre_grid"], out[::4, ::4], g["out_grid"],
+           " | dense 64x64 patch: pre %.2e, image %.4f" % (np.abs(pre[186:250, 480:544] - g["pre_patch"]).max(), np.abs(out[186:250, 480:544] - g["out_patch"]).max()))
 g = T.load_golden("img1_256")
 frame = T.decode_png(g["frame_png"])
 hip.prepare_style(T.decode_png(g["style_png"])); hip.clean(); hip.add(frame); hip.compute()
-out = hip.transfer(O.reflect_pad(frame, 384, 384))[64:320, 64:320]
-pre = hip.preclamp(384, 384)[64:320, 64:320]
-report("img1_256 (data/img_1.jpg, one 256x256 frame, B=1)", hip.get_state(), g["state"], pre[::2, ::2], g["pre_grid"], out[::2, ::2], g["out_grid"])
+for tag, out, pre in both(hip, O.reflect_pad(frame, 384, 384)):
+    out, pre = out[64:320, 64:320], pre[64:320, 64:320]
+    report("img1_256 (data/img_1.jpg, one 256x256 frame, B=1)" + tag, hip.get_state(), g["state"], pre[::2, ::2], g["pre_grid"], out[::2, ::2], g["out_grid"])
 hip.close()
 # round 3: further weight sets
 for v in ("seed1", "dead", "dec4"):
@@ -67,8 +83,8 @@ for v in ("seed1", "dead", "dec4"):
         rows = {r[0]: r[1] for r in T.state_fields(st, g["state_fp64"])}; ref = {r[0]: r[1] for r in T.state_fields(g["state"], g["state_fp64"])}
         extra += " | per field > 1 (HIP / reference float32, both vs float64): " + ", ".join("%s %.1f / %.1f" % (k, rows[k], ref[k]) for k in rows if rows[k] > 1 or ref[k] > 1)
         hip.set_state(g["state"])
-    out = hip.transfer(O.reflect_pad(frames[tid], 192, 192)); pre = hip.preclamp(192, 192)
-    report("global_a_" + v, st, g["state"], pre, g["pre"], out, g["out"], extra)
+    for tag, out, pre in both(hip, O.reflect_pad(frames[tid], 192, 192)):
+        report("global_a_" + v + tag, st, g["state"], pre, g["pre"], out, g["out"], extra)
     hip.close()
 # round 3: the multi-style flow on real images
 g = T.load_golden("real_multistyle")
