@@ -175,14 +175,17 @@ int rrv_release_features(rrv_handle h);
  * 1152 x 1152 x 4 styles: 340 / 339 / 330 frames/s for 1 / 2 / 4 (the two-stream pipeline already fills the chip). */
 int rrv_set_multistyle_group(rrv_handle h, int frames);
 
-/* Kernel choice for the same-resolution 3x3 layers of the per-frame path that have a Winograd F(4x4,3x3) pack (encoder
- * conv1_2 .. conv3_4, ResidualBlock.conv2; test/style_network_global.py:271-281, :104): mode 0 = always F(2x2,3x3);
- * 1 (default, also RRV_F43=) = F(4x4,3x3) where the launch has enough 32 x 32-pixel work items for it to win (from four
- * 640 x 640 frames per launch, two 1152 x 1152 frames; 1.08-1.25x per layer) — a rule on the layer, the batch and the
- * frame size only; 2 = always F(4x4,3x3).  The preparation pass (prepare_style / add / compute) and the frame mode always
- * run F(2x2,3x3).  F(4x4,3x3) rounds 3-6x coarser than F(2x2,3x3) (both inside the stated parity bounds, profiles/
- * r04_parity_margin.txt), so in mode 1 a frame's low-order bits depend on how many frames share its launch; with a
- * fixed mode every entry delivers the same bits for the same frame, and every mode is run-to-run deterministic. */
+/* Kernel choice for the same-resolution 3x3 layers of the per-frame path that have a Winograd F(4x4,3x3) pack (conv_f43_k):
+ * encoder conv1_2 .. conv3_4 (test/style_network_global.py:271-281) and the three ResidualBlock.conv2 (:104,119-122).
+ * mode 0 = always F(2x2,3x3); 1 (default, also RRV_F43=) = F(4x4,3x3) where the launch has enough 32 x 32-pixel work items
+ * for it to win (from four 640 x 640 frames per launch on every packed layer, from two 1152 x 1152 frames, from one where
+ * the items are long; 1.07-1.20x per layer, +8 % frames/s at 512 x 512) — a rule on the layer, the batch and the frame size
+ * only; 2 = always F(4x4,3x3).  The preparation pass (prepare_style / add / compute) and the frame mode always run
+ * F(2x2,3x3).  RRV_F43_LAYERS (bit 0..6 = encoder conv1_2 .. conv3_4, bit 7..9 = slice4 / slice3 / slice2 .conv2; default
+ * all ten) narrows the set.  F(4x4,3x3) rounds ~4x coarser than F(2x2,3x3): worst pre-clamp error over the reference
+ * goldens 0.63 of the stated bound against 0.49 (profiles/r04_parity_margin.txt); in mode 1 a frame's low-order bits
+ * therefore depend on how many frames share its launch; with a fixed mode every entry delivers the same bits for the
+ * same frame, and every mode is run-to-run deterministic. */
 int rrv_set_f43(rrv_handle h, int mode);
 /* Capacity policy of the feature cache (default 64 GiB).  The reference spills every frame's feature to disk
  * (test.py:87-101, cache/%d.pt), so its video length is unbounded; here a cached feature costs 42 MB of HBM per

@@ -34,9 +34,6 @@
 #ifndef F43_ABL
 #define F43_ABL 0
 #endif
-#ifndef F43_STAGGER
-#define F43_STAGGER 0      /* naps of 2048 clocks per chunk of an item and quarter phase (see "Phase stagger" in the kernel) */
-#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -92,86 +89,134 @@ __device__ __forceinline__ void mfma_zero(f32x4& acc, const float a, const float
     else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
 }
 
-// One 1-D input transform B^T (6 -> 6) as TWELVE ops on the lane's channel pair, issued one or two at a time in the
-// gaps between the MFMAs (every instruction of the K loop is a volatile asm: the order written is the order issued).
-// All multipliers are the inline constants +-4, +-2 (the usual -5 is folded away: 4 d0 - 5 d2 + d4 = 4 (d0 - d2) + (d4 - d2)):
-//   0: a = d4 - 4 d2      1: b = d3 - 4 d1      2: c = d4 - d2        3: f = d3 - d1
-//   4: g = d0 - d2        5: d0 = 4 g + c       6: g = d5 - d3        7: d5 = g - 4 f
-//   8: d1 = a + b         9: d2 = a - b        10: d3 = c + 2 f      11: d4 = c - 2 f
-// (t0 = 4 d0 - 5 d2 + d4, t1/t2 = (d4 - 4 d2) +- (d3 - 4 d1), t3/t4 = (d4 - d2) +- 2 (d3 - d1), t5 = 4 d1 - 5 d3 + d5)
-// PK = 1: v_pk_*_f32, one instruction per op (op_sel_hi:[1,0,1] gives both halves the 32-bit inline constant);
-// PK = 0: two plain VALU instructions per op.
-struct F43Tmp { f32x2 a, b, c, f, g; };
-#define F43_FMAK(NAME, KSTR)                                                                                                     \
-    template <int PK>                                                                                                            \
-    __device__ __forceinline__ f32x2 NAME(const f32x2 x, const f32x2 c) { /* x * K + c */                                        \
-        f32x2 r;                                                                                                                 \
-        if constexpr (PK) asm volatile("v_pk_fma_f32 %0, %1, " KSTR ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(c));        \
-        else asm volatile("v_fma_f32 %0, %2, " KSTR ", %4\n\tv_fma_f32 %1, %3, " KSTR ", %5" : "=&v"(r[0]), "=v"(r[1]) : "v"(x[0]), "v"(x[1]), "v"(c[0]), "v"(c[1])); \
-        return r;                                                                                                                \
-    }
-F43_FMAK(t2fma4, "4.0")
-F43_FMAK(t2fmam4, "-4.0")
-F43_FMAK(t2fma2, "2.0")
-F43_FMAK(t2fmam2, "-2.0")
+// ---- the transform matrices.  Interpolation points 0, +-a, +-b, inf with a = 3/4, b = 3/2 instead of the textbook
+// 0, +-1, +-2, inf: in fp32 the error of F(4x4,3x3) is dominated by the accumulation over the input channels in the
+// transform domain, whose values are larger than the outputs by the norms of the transforms; points balanced around 1
+// (A^T entries 0.42 .. 3.4 instead of 1 .. 8, B^T entries <= 2.8 instead of 5) cut that error 2.4x (tools/f43_points.py:
+// 3.0e-6 against 7.1e-6 relative, 256 channels; F(2x2,3x3) 7.2e-7, direct fp32 2.2e-7).  All entries are dyadic
+// rationals, so the algorithm stays exact in real arithmetic with exact fp32 constants.  With A2 = a^2, B2 = b^2,
+// P = a^2 b^2, S = a^2 + b^2:
+//   B^T d:  t0 = P d0 - S d2 + d4          t1, t2 = (d4 - B2 d2) +- a (d3 - B2 d1)
+//           t5 = P d1 - S d3 + d5          t3, t4 = (d4 - A2 d2) +- b (d3 - A2 d1)
+//   A^T m:  y0 = m0 + (m1 + m2) + (m3 + m4)            y1 = a (m1 - m2) + b (m3 - m4)
+//           y2 = A2 (m1 + m2) + B2 (m3 + m4)           y3 = a^3 (m1 - m2) + b^3 (m3 - m4) + m5
+//   G (pack_f43_k, in double): row j = (1, p_j, p_j^2) / prod_{l != j} (p_j - p_l) for the five finite points, (0, 0, 1) for inf.
+// None of the multipliers is an inline constant of the ISA, so each comes from an SGPR pair loaded by an s_mov_b64 with
+// a literal INSIDE the asm statement that uses it (op_sel_hi:[1,0,1] gives both packed halves the low dword; SALU is
+// free next to the vector pipe, and no constant occupies a register across statements: the kernel has none to spare).
+constexpr float F43_A = 0.75f, F43_B = 1.5f;
+constexpr float F43_A2 = F43_A * F43_A, F43_B2 = F43_B * F43_B, F43_P = F43_A2 * F43_B2, F43_S = F43_A2 + F43_B2;
+constexpr float F43_A3 = F43_A2 * F43_A, F43_B3 = F43_B2 * F43_B;
+constexpr unsigned f43_bits(float f) { return __builtin_bit_cast(unsigned, f); }
+
+// r = x * (+-K) + c on a channel pair, K = the float with bit pattern KB
+template <unsigned KB, bool NEG>
+__device__ __forceinline__ f32x2 t2fmak(const f32x2 x, const f32x2 c) {
+    f32x2 r;
+    unsigned long long ks;
+    if constexpr (NEG) asm volatile("s_mov_b64 %1, %4\n\tv_pk_fma_f32 %0, %2, %1, %3 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r), "=&s"(ks) : "v"(x), "v"(c), "i"(KB));
+    else asm volatile("s_mov_b64 %1, %4\n\tv_pk_fma_f32 %0, %2, %1, %3 op_sel_hi:[1,0,1]" : "=v"(r), "=&s"(ks) : "v"(x), "v"(c), "i"(KB));
+    return r;
+}
+template <unsigned KB>
+__device__ __forceinline__ f32x2 t2mulk(const f32x2 x) {      // x * K
+    f32x2 r;
+    unsigned long long ks;
+    asm volatile("s_mov_b64 %1, %3\n\tv_pk_mul_f32 %0, %2, %1 op_sel_hi:[1,0]" : "=v"(r), "=&s"(ks) : "v"(x), "i"(KB));
+    return r;
+}
 template <int PK>
 __device__ __forceinline__ f32x2 t2add(const f32x2 x, const f32x2 y) {
     f32x2 r;
-    if constexpr (PK) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    else asm volatile("v_add_f32 %0, %2, %4\n\tv_add_f32 %1, %3, %5" : "=&v"(r[0]), "=v"(r[1]) : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
 template <int PK>
 __device__ __forceinline__ f32x2 t2sub(const f32x2 x, const f32x2 y) {
     f32x2 r;
-    if constexpr (PK) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
-    else asm volatile("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %5" : "=&v"(r[0]), "=v"(r[1]) : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
-template <int OP, int PK>
-__device__ __forceinline__ void f43_op(F43Tmp& t, f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
-    if constexpr (OP == 0) t.a = t2fmam4<PK>(d2, d4);
-    if constexpr (OP == 1) t.b = t2fmam4<PK>(d1, d3);
-    if constexpr (OP == 2) t.c = t2sub<PK>(d4, d2);
-    if constexpr (OP == 3) t.f = t2sub<PK>(d3, d1);
-    if constexpr (OP == 4) t.g = t2sub<PK>(d0, d2);
-    if constexpr (OP == 5) d0 = t2fma4<PK>(t.g, t.c);
-    if constexpr (OP == 6) t.g = t2sub<PK>(d5, d3);
-    if constexpr (OP == 7) d5 = t2fmam4<PK>(t.f, t.g);
-    if constexpr (OP == 8) d1 = t2add<PK>(t.a, t.b);
-    if constexpr (OP == 9) d2 = t2sub<PK>(t.a, t.b);
-    if constexpr (OP == 10) d3 = t2fma2<PK>(t.f, t.c);
-    if constexpr (OP == 11) d4 = t2fmam2<PK>(t.f, t.c);
+// SIX independent lines, one op of the 1-D input transform each, in ONE asm statement: r[n] = x[n] * (+-K) + c[n].  The six
+// packed FMAs share one constant load, and the five instructions behind an op never need its result (a dependent packed
+// op would wait ~9 cycles, an independent one issues in ~4).  Outputs are early-clobber: they are written while later
+// lines' inputs are still to be read.
+template <unsigned KB, bool NEG>
+__device__ __forceinline__ void fmak6(f32x2& r0, f32x2& r1, f32x2& r2, f32x2& r3, f32x2& r4, f32x2& r5,
+                                      const f32x2 x0, const f32x2 x1, const f32x2 x2, const f32x2 x3, const f32x2 x4, const f32x2 x5,
+                                      const f32x2 c0, const f32x2 c1, const f32x2 c2, const f32x2 c3, const f32x2 c4, const f32x2 c5) {
+    unsigned long long ks;
+#define F43_L(N, X, C) "v_pk_fma_f32 %" #N ", %" #X ", %6, %" #C " op_sel_hi:[1,0,1]"
+#define F43_LN(N, X, C) F43_L(N, X, C) " neg_lo:[0,1,0] neg_hi:[0,1,0]"
+    if constexpr (NEG)
+        asm volatile("s_mov_b64 %6, %19\n\t" F43_LN(0, 7, 13) "\n\t" F43_LN(1, 8, 14) "\n\t" F43_LN(2, 9, 15) "\n\t" F43_LN(3, 10, 16) "\n\t" F43_LN(4, 11, 17) "\n\t" F43_LN(5, 12, 18)
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&s"(ks)
+                     : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "i"(KB));
+    else
+        asm volatile("s_mov_b64 %6, %19\n\t" F43_L(0, 7, 13) "\n\t" F43_L(1, 8, 14) "\n\t" F43_L(2, 9, 15) "\n\t" F43_L(3, 10, 16) "\n\t" F43_L(4, 11, 17) "\n\t" F43_L(5, 12, 18)
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&s"(ks)
+                     : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "i"(KB));
+#undef F43_L
+#undef F43_LN
 }
-template <int PK>
-__device__ __forceinline__ void f43_in_all(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
-    F43Tmp t;
-    static_for([&](auto oc) { f43_op<decltype(oc)::value, PK>(t, d0, d1, d2, d3, d4, d5); }, std::make_integer_sequence<int, 12>{});
-}
-// SIX independent 1-D transforms (all columns, or all rows, of a patch), op by op in lockstep: the five instructions
-// behind an op never need its result (a dependent packed op would wait ~9 cycles, an independent one issues in ~4).
+// The 1-D input transform B^T (6 -> 6) of SIX lines (all columns, or all rows, of a patch) as twelve ops in lockstep:
+//   0: A = d4 - B2 d2     1: B = d3 - B2 d1     2: C = d4 - A2 d2     3: F = d3 - A2 d1
+//   4: g = P d0 + d4      5: d0 = g - S d2      6: g = P d1 + d5      7: d5 = g - S d3
+//   8: d1 = A + a B       9: d2 = A - a B      10: d3 = C + b F      11: d4 = C - b F
 // L(n, j) = element j of line n.
+struct F43Tmp { f32x2 a, b, c, f, g; };
 template <int PK, class LineFn>
 __device__ __forceinline__ void f43_in6(LineFn&& L) {
     F43Tmp t[6];
-    static_for([&](auto oc) {
-        constexpr int op = decltype(oc)::value;
-        static_for([&](auto nc) {
-            constexpr int n = decltype(nc)::value;
-            f43_op<op, PK>(t[n], L(nc, std::integral_constant<int, 0>{}), L(nc, std::integral_constant<int, 1>{}), L(nc, std::integral_constant<int, 2>{}),
-                           L(nc, std::integral_constant<int, 3>{}), L(nc, std::integral_constant<int, 4>{}), L(nc, std::integral_constant<int, 5>{}));
-        }, std::make_integer_sequence<int, 6>{});
-    }, std::make_integer_sequence<int, 12>{});
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+#define F43_D(J) L(I0{}, I##J{}), L(I1{}, I##J{}), L(I2{}, I##J{}), L(I3{}, I##J{}), L(I4{}, I##J{}), L(I5{}, I##J{})
+#define F43_T(M) t[0].M, t[1].M, t[2].M, t[3].M, t[4].M, t[5].M
+    fmak6<f43_bits(F43_B2), true>(F43_T(a), F43_D(2), F43_D(4));
+    fmak6<f43_bits(F43_B2), true>(F43_T(b), F43_D(1), F43_D(3));
+    fmak6<f43_bits(F43_A2), true>(F43_T(c), F43_D(2), F43_D(4));
+    fmak6<f43_bits(F43_A2), true>(F43_T(f), F43_D(1), F43_D(3));
+    fmak6<f43_bits(F43_P), false>(F43_T(g), F43_D(0), F43_D(4));
+    fmak6<f43_bits(F43_S), true>(F43_D(0), F43_D(2), F43_T(g));
+    fmak6<f43_bits(F43_P), false>(F43_T(g), F43_D(1), F43_D(5));
+    fmak6<f43_bits(F43_S), true>(F43_D(5), F43_D(3), F43_T(g));
+    fmak6<f43_bits(F43_A), false>(F43_D(1), F43_T(b), F43_T(a));
+    fmak6<f43_bits(F43_A), true>(F43_D(2), F43_T(b), F43_T(a));
+    fmak6<f43_bits(F43_B), false>(F43_D(3), F43_T(f), F43_T(c));
+    fmak6<f43_bits(F43_B), true>(F43_D(4), F43_T(f), F43_T(c));
+#undef F43_D
+#undef F43_T
 }
-// 1-D output transform A^T (6 -> 4) on a channel pair:
-//   y0 = m0 + (m1 + m2) + (m3 + m4)     y1 = (m1 - m2) + 2 (m3 - m4)     y2 = (m1 + m2) + 4 (m3 + m4)     y3 = (m1 - m2) + 8 (m3 - m4) + m5
+// 1-D output transform A^T (6 -> 4) on a channel pair (see the matrices above): twelve packed ops and six constant loads in
+// ONE asm statement (the compiler pads every asm boundary with wait states it cannot prove unnecessary), ordered so that
+// no op needs the result of the three before it.
 __device__ __forceinline__ void f43_out(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
                                         f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3) {
-    const f32x2 s1 = t2add<1>(m1, m2), d1 = t2sub<1>(m1, m2), s2 = t2add<1>(m3, m4), d2 = t2sub<1>(m3, m4);
-    y0 = t2add<1>(t2add<1>(m0, s1), s2);
-    y1 = t2fma2<1>(d2, d1);
-    y2 = t2fma4<1>(s2, s1);
-    y3 = t2add<1>(t2fma4<1>(d2, t2fma4<1>(d2, d1)), m5);      // 8 is no inline constant: 4 d2 + (4 d2 + d1)
+    f32x2 s1, d1, s2, d2;
+    unsigned long long ks;
+    asm volatile(
+        "v_pk_add_f32 %[s1], %[m1], %[m2]\n\t"
+        "v_pk_add_f32 %[d1], %[m1], %[m2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[s2], %[m3], %[m4]\n\t"
+        "v_pk_add_f32 %[d2], %[m3], %[m4] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[y0], %[m0], %[s1]\n\t"
+        "s_mov_b64 %[k], %[ka]\n\t"
+        "v_pk_mul_f32 %[y1], %[d1], %[k] op_sel_hi:[1,0]\n\t"
+        "s_mov_b64 %[k], %[ka2]\n\t"
+        "v_pk_mul_f32 %[y2], %[s1], %[k] op_sel_hi:[1,0]\n\t"
+        "s_mov_b64 %[k], %[ka3]\n\t"
+        "v_pk_fma_f32 %[y3], %[d1], %[k], %[m5] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_add_f32 %[y0], %[y0], %[s2]\n\t"
+        "s_mov_b64 %[k], %[kb]\n\t"
+        "v_pk_fma_f32 %[y1], %[d2], %[k], %[y1] op_sel_hi:[1,0,1]\n\t"
+        "s_mov_b64 %[k], %[kb2]\n\t"
+        "v_pk_fma_f32 %[y2], %[s2], %[k], %[y2] op_sel_hi:[1,0,1]\n\t"
+        "s_mov_b64 %[k], %[kb3]\n\t"
+        "v_pk_fma_f32 %[y3], %[d2], %[k], %[y3] op_sel_hi:[1,0,1]"
+        : [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3), [s1] "=&v"(s1), [d1] "=&v"(d1), [s2] "=&v"(s2), [d2] "=&v"(d2), [k] "=&s"(ks)
+        : [m0] "v"(m0), [m1] "v"(m1), [m2] "v"(m2), [m3] "v"(m3), [m4] "v"(m4), [m5] "v"(m5),
+          [ka] "i"(f43_bits(F43_A)), [ka2] "i"(f43_bits(F43_A2)), [ka3] "i"(f43_bits(F43_A3)),
+          [kb] "i"(f43_bits(F43_B)), [kb2] "i"(f43_bits(F43_B2)), [kb3] "i"(f43_bits(F43_B3)));
 }
 
 template <int EPI>
@@ -408,15 +453,6 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         next_patch();
         __syncthreads();      // round-3 fix, as in the library kernels: raw(0) is read by every wave before the first chunk's LDS-DMA reuses its buffer
     }
-    // Phase stagger: every workgroup runs the same item stream (K loop without stores, then a 128 KB store burst), and
-    // workgroups that start together stay in lockstep — all 256 CUs then store at the same time at more than the HBM
-    // rate and every epilogue waits.  Workgroup w starts a quarter / half / three quarters of an item late (w / 8 mod 4:
-    // the XCD neighbours differ), once per launch.
-    if (F43_STAGGER && have) {
-        const int skew = (blockIdx.x >> 3) & 3;
-        const int naps = skew * nchunks * F43_STAGGER;        // x 64 x 32 clocks
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);
-    }
     if (ABL & 16) tl_t = clock64();
     while (have) {
         const int e_y0 = (cur.ty + p.ty0) * 32, e_x0 = (cur.tx + p.tx0) * 32, e_b = cur.b, e_ntile = cur.nt;
@@ -504,39 +540,73 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                         for (int i = 0; i < 4; ++i) Y0[i][j] = Y[i];
                         continue;
                     }
-                    const f32x4 bias = *(const f32x4*)(pl);
+                    // The four pixels (i = 0..3) of column j go through the epilogue STAGE by stage: each per-channel parameter
+                    // vector is read from LDS once per column and applied to four independent values (one wave per SIMD: a
+                    // pixel-by-pixel chain would re-read all ten vectors per pixel and wait for LDS ~300 times per item).
                     f32x4 o4[4];
+                    {
+                        const f32x4 bias = *(const f32x4*)(pl);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o4[i] = e4add(f32x4{Y0[i][j][0], Y0[i][j][1], Y[i][0], Y[i][1]}, bias);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        f32x4 o = e4add(f32x4{Y0[i][j][0], Y0[i][j][1], Y[i][0], Y[i][1]}, bias);
-                        if (EPI & E_RELU) o = f4relu(o);
-                        if (EPI & E_LRELU) o = f4lrelu(o);
-                        if (EPI & E_NORM1) o = f4norm_clamp(o, *(const f32x4*)(pl + 128), *(const f32x4*)(pl + 256), *(const f32x4*)(pl + 384), *(const f32x4*)(pl + 512));
-                        if constexpr ((EPI & E_RES_UPS) != 0) o = e4add(o, rres[i >> 1][j >> 1]);
-                        if (EPI & E_NORM2)
-                            o = e4fma(f4norm_clamp(o, *(const f32x4*)(pl + 640), *(const f32x4*)(pl + 768), *(const f32x4*)(pl + 896), *(const f32x4*)(pl + 1024)),
-                                      *(const f32x4*)(pl + 1280), *(const f32x4*)(pl + 1152));
-                        o4[i] = o;
+                        if (EPI & E_RELU) o4[i] = f4relu(o4[i]);
+                        if (EPI & E_LRELU) o4[i] = f4lrelu(o4[i]);
+                    }
+                    auto norm_clamp4 = [&](const char* q) {      // InstanceNorm.forward with the saved statistics at q: (x - mean) * rstd, clamped
+                        {
+                            const f32x4 m = *(const f32x4*)(q), r = *(const f32x4*)(q + 128);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o4[i] = e4mul(f4sub(o4[i], m), r);
+                        }
+                        const f32x4 lo = *(const f32x4*)(q + 256), hi = *(const f32x4*)(q + 384);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o4[i][e] = med3(o4[i][e], lo[e], hi[e]);
+                    };
+                    if (EPI & E_NORM1) norm_clamp4(pl + 128);
+                    if constexpr ((EPI & E_RES_UPS) != 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o4[i] = e4add(o4[i], rres[i >> 1][j >> 1]);
+                    }
+                    if (EPI & E_NORM2) {
+                        norm_clamp4(pl + 640);
+                        const f32x4 sstd = *(const f32x4*)(pl + 1280), smean = *(const f32x4*)(pl + 1152);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o4[i] = e4fma(o4[i], sstd, smean);
                     }
                     if constexpr (POOL) {
+                        f32x4 m2[2];
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            f32x4 m;
+                        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) m[e] = fmaxf(o4[2 * a][e], o4[2 * a + 1][e]);
-                            if ((j & 1) == 0) { pool_prev[a] = m; continue; }
+                            for (int e = 0; e < 4; ++e) m2[a][e] = fmaxf(o4[2 * a][e], o4[2 * a + 1][e]);
+                        if ((j & 1) == 0) { pool_prev[0] = m2[0]; pool_prev[1] = m2[1]; continue; }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], pool_prev[a][e]);
-                            char* const dst = sb + (a * rowb + (j >> 1) * pixb + nb * 64);
-                            if (ABL & 4) { if (m[0] == 123.456f) *(float*)(dst + st_off) = m[0]; }
-                            else if (interior || ((yb >> 1) + a < Ho && (xb >> 1) + (j >> 1) < Wo)) *(f32x4*)(dst + st_off) = m;
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m2[a][e] = fmaxf(m2[a][e], pool_prev[a][e]);
+                        char* const dst = sb + ((j >> 1) * pixb + nb * 64) + st_off;
+                        if (ABL & 4) { if (m2[0][0] == 123.456f) *(float*)dst = m2[0][0] + m2[1][0]; }
+                        else if (interior) {                                     // wave-uniform: the whole item lies inside the image
+                            *(f32x4*)dst = m2[0]; *(f32x4*)(dst + rowb) = m2[1];
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+                                if ((yb >> 1) + a < Ho && (xb >> 1) + (j >> 1) < Wo) *(f32x4*)(dst + a * rowb) = m2[a];
                         }
                     } else {
+                        char* const dst = sb + (j * pixb + nb * 64) + st_off;
+                        if (ABL & 4) { if (o4[0][0] == 123.456f) *(float*)dst = o4[0][0] + o4[1][0] + o4[2][0] + o4[3][0]; }
+                        else if (interior) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            char* const dst = sb + (i * rowb + j * pixb + nb * 64);
-                            if (ABL & 4) { if (o4[i][0] == 123.456f) *(float*)(dst + st_off) = o4[i][0]; }
-                            else if (interior || (yb + i < p.H && xb + j < p.W)) *(f32x4*)(dst + st_off) = o4[i];
+                            for (int i = 0; i < 4; ++i) *(f32x4*)(dst + i * rowb) = o4[i];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (yb + i < p.H && xb + j < p.W) *(f32x4*)(dst + i * rowb) = o4[i];
                         }
                     }
                 }
@@ -569,19 +639,19 @@ __global__ void pack_f43_k(const float* __restrict__ w, float* __restrict__ dst,
         const int co = n_tile * 32 + row, ci = chunk * 8 + 2 * pair + (fl & 1);
         const float* g = w + ((size_t)co * Cin + ci) * 9;
         const int pr = pos / 6, pc = pos % 6;
-        auto G3 = [](int rw, float g0, float g1, float g2) -> float {
-            switch (rw) {
-                case 0: return 0.25f * g0;
-                case 1: return (-1.f / 6.f) * (g0 + g1 + g2);
-                case 2: return (-1.f / 6.f) * (g0 - g1 + g2);
-                case 3: return (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-                case 4: return (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-                default: return g2;
-            }
+        // U = G g G^T in double, rounded once.  G row j = (1, p_j, p_j^2) / prod_{l != j} (p_j - p_l) for the finite points
+        // 0, +a, -a, +b, -b (in this order: the positions of the transforms above), (0, 0, 1) for the point at infinity.
+        auto G3 = [](int rw, double g0, double g1, double g2) -> double {
+            const double A = (double)F43_A, B = (double)F43_B;
+            const double pt[5] = {0.0, A, -A, B, -B};
+            if (rw == 5) return g2;
+            double N = 1.0;
+            for (int l = 0; l < 5; ++l) if (l != rw) N *= pt[rw] - pt[l];
+            return (g0 + pt[rw] * g1 + pt[rw] * pt[rw] * g2) / N;
         };
-        float rowv[3];   // (G g)[pr][kx]
+        double rowv[3];   // (G g)[pr][kx]
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) rowv[kx] = G3(pr, g[0 * 3 + kx], g[1 * 3 + kx], g[2 * 3 + kx]);
-        dst[i] = G3(pc, rowv[0], rowv[1], rowv[2]);
+        dst[i] = (float)G3(pc, rowv[0], rowv[1], rowv[2]);
     }
 }

@@ -1,8 +1,11 @@
-"""GPU tests (-m gpu) of the F(4x4,3x3) kernel choice (conv_f43_k; rrv_set_f43, include/rerevst_hip.h): the library's
-default runs the same-resolution 3x3 layers of the per-frame path in F(4x4,3x3) when a launch carries >= 4 frames.
-The rest of the GPU suite pins RRV_F43=0 (tests/conftest.py) — its cross-entry bit-identity invariants hold for a
-FIXED kernel choice — so this module is where the default choice (mode 1) and the F(4x4,3x3) kernels themselves
-(mode 2: every launch) meet the reference goldens, the oracle, partial tiles, the crop windows and the debug mode."""
+"""GPU tests (-m gpu) of the F(4x4,3x3) kernel choice (conv_f43_k; rrv_set_f43, include/rerevst_hip.h): by default the
+library runs the encoder convs conv1_2 .. conv3_4 and the three ResidualBlock.conv2 in F(4x4,3x3) when a launch has
+enough work items.  The rest of the GPU suite pins RRV_F43=0 (tests/conftest.py) — its cross-entry bit-identity
+invariants hold for a FIXED kernel choice — so this module is where the default choice (mode 1) and the kernel on every
+packed layer in every launch (mode 2) meet the reference goldens, the oracle, partial tiles, the crop windows and the
+debug mode."""
+import os
+
 import numpy as np
 import pytest
 
@@ -45,13 +48,14 @@ def test_f43_meets_the_reference_goldens(pkg, weights, oracle):
     assert not np.array_equal(ref, out)                          # the other kernels really ran
     s.set_f43(1)
     np.testing.assert_array_equal(_batched(s, oracle.reflect_pad(frames[tid], 192, 192))[0], ref)     # default rule: too few work items at 192 x 192 x 4
+    np.testing.assert_array_equal(s.transfer(oracle.reflect_pad(frames[tid], 192, 192)), ref)
     g = load_golden("real_default")                               # the reference's default invocation: 436 x 1024 in 576 x 1152
     s.set_state(g["state"])
     frame = decode_png(g["frame%d_png" % int(g["transfer_id"])])
     padded = oracle.reflect_pad(frame, 576, 1152)
     out, pre = _batched(s, padded)                                # mode 1, four frames per launch
     s.set_f43(2)
-    np.testing.assert_array_equal(s.transfer(padded), out)        # = conv_f43_k on every packed layer
+    np.testing.assert_array_equal(s.transfer(padded), out)        # = conv_f43_k on the shipped layer set in every launch
     s.set_f43(1)
     out, pre = out[64:500, 64:1088], pre[64:500, 64:1088]
     assert_pre_close(pre[::4, ::4], g["pre_grid"])
@@ -89,8 +93,11 @@ def test_preparation_pass_never_uses_f43(pkg, weights, oracle):
     np.testing.assert_array_equal(states[0], states[1])
 
 
-def test_fixed_choice_is_bit_identical_across_entries(hip, pkg, oracle):
-    """Mode 2 (conv_f43_k in every launch): one frame per call == batched == tickets == pad/crop entry, bit for bit."""
+def test_fixed_choice_is_bit_identical_across_entries(pkg, weights, oracle, all_f43_layers):
+    """Mode 2 (conv_f43_k in every launch, all ten packed layers): one frame per call == batched == tickets == pad/crop
+    entry, bit for bit."""
+    hip = pkg.Stylization(weights, cuda=True)
+    hip.set_state(load_golden("global_a")["state"])
     hip.set_f43(2)
     try:
         PH, PW = oracle.padded_size(72), oracle.padded_size(100)    # ReshapeTool: 256 x 256 — what transfer_frames pads to on the device
@@ -115,13 +122,26 @@ def test_fixed_choice_is_bit_identical_across_entries(hip, pkg, oracle):
             again = hip.transfer_batch(frames)
             np.testing.assert_array_equal(again, batch)
     finally:
-        hip.set_f43(0)
+        hip.close()
+
+
+@pytest.fixture
+def all_f43_layers():
+    """Handles created inside run conv_f43_k on all ten packed layers (the encoder's ReLU and ReLU + pool epilogues too)."""
+    old = os.environ.get("RRV_F43_LAYERS")
+    os.environ["RRV_F43_LAYERS"] = "0x3ff"
+    yield
+    if old is None:
+        del os.environ["RRV_F43_LAYERS"]
+    else:
+        os.environ["RRV_F43_LAYERS"] = old
 
 
 @pytest.mark.parametrize("hw", [(200, 136), (77, 90), (40, 56), (33, 31), (8, 8), (264, 40)])
-def test_f43_partial_tiles_vs_oracle(hw, pkg, oracle, weights):
+def test_f43_partial_tiles_vs_oracle(hw, pkg, oracle, weights, all_f43_layers):
     """Frame sizes that leave partial 32 x 32 work items, partial 4 x 4 tiles and odd pooling sizes at every level, every
-    conv_f43_k epilogue (ReLU, ReLU + pool, LeakyReLU + norm + half-resolution residual + AdaIN): against the oracle."""
+    conv_f43_k epilogue (ReLU, ReLU + pool, LeakyReLU + norm + half-resolution residual + AdaIN): against the oracle.
+    Regular bounds."""
     H, W = hw
     style = pkg.synth_style(48, 40, kind="smooth", seed=11)
     frames = [pkg.synth_frame(40 + i, H, W, kind="smooth") for i in range(3)]
@@ -145,7 +165,7 @@ def test_f43_partial_tiles_vs_oracle(hw, pkg, oracle, weights):
     s.close()
 
 
-def test_f43_under_the_bounds_checked_debug_mode(pkg, weights, oracle):
+def test_f43_under_the_bounds_checked_debug_mode(pkg, weights, oracle, all_f43_layers):
     """Every conv_f43_k launch verified (guard bands, zero ring, slack rows): same bits as the unchecked run."""
     s = pkg.Stylization(weights, cuda=True)
     s.set_state(load_golden("global_a")["state"])

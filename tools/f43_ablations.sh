@@ -10,11 +10,7 @@ if [ "$1" = build ]; then
     for v in $VARIANTS; do
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DF43_ABL=$v tools/f43_bench.hip -o tools/bin/f43_bench_$v &
     done
-    for st in 1 2; do
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DF43_STAGGER=$st tools/f43_bench.hip -o tools/bin/f43_bench_stagger$st &
-    done
     wait
 else
-    for st in 1 2; do echo "== F43_STAGGER=$st"; tools/bin/f43_bench_stagger$st; done
     for v in $VARIANTS; do echo "== F43_ABL=$v"; tools/bin/f43_bench_$v; done
 fi

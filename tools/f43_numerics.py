@@ -5,9 +5,13 @@ import state_bounds as C
 import rerevst_oracle as O
 pkg = importlib.import_module("rerevst-code_amd")
 F32=np.float32
-BT=np.array([[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]],F32)
-G=np.array([[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]],F32)
-AT=np.array([[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]],F32)
+# the kernel's interpolation points 0, +-3/4, +-3/2, inf (rerevst-code_amd/csrc/conv_f43.h; matrices from tools/f43_points.py)
+import importlib.util, os
+_spec = importlib.util.spec_from_file_location("f43_points", os.path.join(os.path.dirname(os.path.abspath(__file__)), "f43_points.py"))
+_fp = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_fp)
+_AT, _G, _BT = _fp.cook_toom([0, .75, -.75, 1.5, -1.5])
+BT=_BT.astype(F32); AT=_AT.astype(F32)
+G=_G          # float64: the weight transform is evaluated in double and rounded once (pack_f43_k)
 orig=O.conv3x3
 MODE={"layers":"all"}
 def conv_f43(x,w,b=None):
@@ -16,7 +20,7 @@ def conv_f43(x,w,b=None):
     th,tw=(H+3)//4,(W+3)//4
     xp=np.zeros((Bn,th*4+2,tw*4+2,Cin),F32); xp[:,1:H+1,1:W+1]=x
     # U = G g G^T  [36][Cin][Cout]
-    U=np.einsum('ia,ocab,jb->ijco',G,w.astype(F32),G,optimize=True).astype(F32).reshape(36,Cin,Cout)
+    U=np.einsum('ia,ocab,jb->ijco',G,w.astype(np.float64),G,optimize=True).astype(F32).reshape(36,Cin,Cout)
     out=np.zeros((Bn,th*4,tw*4,Cout),F32)
     for bi in range(Bn):
         # patches [th,tw,6,6,Cin]

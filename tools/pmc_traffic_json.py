@@ -30,7 +30,9 @@ def per_kernel(path, counter):
 
 def fetch_factor(name):
     """Bytes per FETCH_SIZE byte for the kernel's read pattern (see the module docstring)."""
-    if name.startswith(("void conv_wino_k", "void conv_wino_split_k", "void conv_f43_k", "void conv_mfma_k")):
+    if name.startswith("void conv_f43_k"):
+        return 0.5          # LDS-DMA of 8-channel chunks: the raw halo (what misses L2) arrives in 32-byte segments
+    if name.startswith(("void conv_wino_k", "void conv_wino_split_k", "void conv_mfma_k")):
         return 1.0          # LDS-DMA of 16-channel chunks: 64-byte segments
     return 2.0              # conv_last_k (256-byte pixels), conv_first_k, streaming float4 kernels, blit copies
 
