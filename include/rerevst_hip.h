@@ -184,8 +184,10 @@ int rrv_set_multistyle_group(rrv_handle h, int frames);
  * F(2x2,3x3).  RRV_F43_LAYERS (bit 0..6 = encoder conv1_2 .. conv3_4, bit 7..9 = slice4 / slice3 / slice2 .conv2; default
  * all ten) narrows the set.  F(4x4,3x3) rounds ~4x coarser than F(2x2,3x3): worst pre-clamp error over the reference
  * goldens 0.63 of the stated bound against 0.49 (profiles/r04_parity_margin.txt); in mode 1 a frame's low-order bits
- * therefore depend on how many frames share its launch; with a fixed mode every entry delivers the same bits for the
- * same frame, and every mode is run-to-run deterministic. */
+ * therefore depend on how many frames share its launch; with a fixed mode every single-style entry delivers the same bits for
+ * the same frame, and every mode is run-to-run deterministic.  The multi-style feature cache (rrv_generate_content_features)
+ * and the grouped per-image-state launches (rrv_set_multistyle_group > 1) always run F(2x2,3x3), so in modes 1 / 2 a blended
+ * rrv_transfer_blend of a frame and rrv_transfer_features of its cached feature differ by the kernels' rounding. */
 int rrv_set_f43(rrv_handle h, int mode);
 /* Capacity policy of the feature cache (default 64 GiB).  The reference spills every frame's feature to disk
  * (test.py:87-101, cache/%d.pt), so its video length is unbounded; here a cached feature costs 42 MB of HBM per

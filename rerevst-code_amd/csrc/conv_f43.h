@@ -27,7 +27,7 @@
 //
 // F43_ABL (default 0; tools/f43_bench.hip builds one binary per value): microbenchmark switches — 1 no LDS-DMA after the
 // first stage, 2 no K-loop barriers, 4 no stores, 8 no input transform, 16 per-phase clock64 timeline into p.dbg, 32 no
-// epilogue.  The library is compiled with 0: every hook is a discarded constexpr branch.
+// epilogue, 64 the two halves of every output line stored back to back (wrong results; what the time between them costs).  The library is compiled with 0: every hook is a discarded constexpr branch.
 #pragma once
 #include "conv_wino.h"
 
@@ -600,6 +600,12 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                     } else {
                         char* const dst = sb + (j * pixb + nb * 64) + st_off;
                         if (ABL & 4) { if (o4[0][0] == 123.456f) *(float*)dst = o4[0][0] + o4[1][0] + o4[2][0] + o4[3][0]; }
+                        else if (ABL & 64) {      // microbench only (wrong results): both 64-byte halves of every 128-byte line stored back to back
+                            if (nb == 1) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { *(f32x4*)(dst + i * rowb - 64) = o4[i]; *(f32x4*)(dst + i * rowb) = o4[i]; }
+                            }
+                        }
                         else if (interior) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) *(f32x4*)(dst + i * rowb) = o4[i];

@@ -445,6 +445,15 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
         tick(3);                              // K loop
         // the next item's first tiles were requested by the last two chunks
         cur = nxt; have = have_nxt; in_t = in_n; w_t = w_n;
+        if constexpr ((ABL & 32) != 0) {      // microbench only: no epilogue (the accumulators stay alive)
+            f32x4 sacc = acc[0][0];
+#pragma unroll
+            for (int i = 0; i < NPU; ++i)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) if (i || nb) sacc += acc[i][nb];
+            if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 123.456f) p.out[tid] = sacc[0];
+            continue;
+        }
         // ---- output transform + fused epilogue (all in registers)
         float* out_b = p.out + (size_t)e_b * (size_t)(p.H + 2) * (p.W + 2) * p.Cout;
         const float* res_b = nullptr;
