@@ -7,7 +7,7 @@
 `value` is HOST -> HOST, as SURVEY.md §8(d) defines the metric and as the reference's transfer() works
 (test/framework.py:109 `.to(device)` ... :40 `.cpu()`): a step = one `rrv_transfer_batch` call over `--batch`
 synthetic SxS frames per GPU (reflect-padded to P = roundup64(S+128) as generate_real_video.py:61-83 does), uint8
-frames in (page-locked) host memory -> float32 BGR frames in (page-locked) host memory; the sub-batches of 8 are
+frames in (page-locked) host memory -> float32 BGR frames in (page-locked) host memory; the sub-batches of 16 are
 pipelined inside the call (H2D / kernels / D2H on two HIP streams).  Extras, never `value`: the HBM -> HBM rate of
 the same frames (`device_resident_frames_per_s`), the rate with pageable caller arrays, and the unpadded-in /
 cropped-out entry.
@@ -345,7 +345,7 @@ def main():
     # (150 per GPU; kept for every N > 1 so that the work per GPU — and rank 0's preparation per GPU — is the same)
     NF = args.frames or ({256: 100}.get(S, 300) if world == 1 else {256: 100}.get(S, 150) * world)
     P = video.padded_size(S)
-    B = args.batch or max(8, min(128, (64 * 640 * 640) // (P * P) // 8 * 8))
+    B = args.batch or max(8, min(128, (128 * 640 * 640) // (P * P) // 8 * 8))      # 128 frames per call at 512x512 (eight sub-batches of 16), 128 at 256x256, 32 at 1024x1024
     weights = pkg.synthetic_weights(0)
 
     def barrier():
@@ -484,7 +484,7 @@ def main():
                "config": {"workload": what, "entry": ("rrv_transfer_features_batch: relu4_1 features in HBM -> float32 frames in %s host memory" if NS else
                                                       "rrv_transfer_batch: uint8 frames in %s host memory -> float32 frames in the same (H2D + kernels + D2H)")
                                                % ("pageable" if args.pageable else "page-locked"),
-                          "frames_per_step_per_gpu": B, "sub_batch": MS_GROUP if NS else max(1, min(32, B, (8 * 640 * 640) // (P * P))), "batches_in_flight": args.pipeline,
+                          "frames_per_step_per_gpu": B, "sub_batch": MS_GROUP if NS else max(1, min(32, B, (16 * 640 * 640) // (P * P))), "batches_in_flight": args.pipeline,
                           "sampled_frames": len(video.sample_indices_multistyle(NF, 16) if NS else video.sample_indices(NF)),
                           "parallelism": "frame-shard x%d" % world},
                "ms_per_frame": round(1e3 * dt / args.steps / B, 4), "roofline": roof, "cpu_baseline": cpu,
@@ -500,9 +500,10 @@ def main():
             # a video end to end = the caching pass (encoder, once per frame) THEN the decoder pass: serial rates combine harmonically
             out["end_to_end_frames_per_s"] = round(1.0 / (1.0 / fc + 1.0 / out["value"]), 1)
         if world == 1 and not args.no_extras and not NS:
-            # extras, NOT `value`.  (1) HBM -> HBM on the same frames, 8 per launch, two batches in flight (round 1's headline)
-            d_in = torch.from_numpy(np.ascontiguousarray(h_in[0][:16 if B >= 16 else B])).to(dev)
-            nb8 = max(1, d_in.shape[0] // 8)
+            # extras, NOT `value`.  (1) HBM -> HBM on the same frames, one sub-batch per launch, two batches in flight (round 1's headline)
+            sbf = max(1, min(32, B, (16 * 640 * 640) // (P * P)))       # the library's sub-batch for this frame size
+            d_in = torch.from_numpy(np.ascontiguousarray(h_in[0][:2 * sbf if B >= 2 * sbf else B])).to(dev)
+            nb8 = max(1, d_in.shape[0] // sbf)
             bb = d_in.shape[0] // nb8
             d_in = d_in[:nb8 * bb].view(nb8, bb, P, P, 3)
             d_out = torch.empty((4, bb, P, P, 3), dtype=torch.float32, device=dev)

@@ -1926,7 +1926,16 @@ static int host_roundtrip(rrv_handle h, const uint8_t* frames, int B, int H, int
 // sub-batch k+1.. (copy_in stream), the kernels of k and k+1 (the two compute streams), the D2H copy of k-1 (copy_out
 // stream); events order a set's H2D -> kernels -> D2H and its re-use four sub-batches later.  With pageable caller
 // arrays the host additionally copies into / out of the pinned staging buffers while all of that runs.
-constexpr long HOST_SUB_PIXELS = 8L * 640 * 640;      // pixels per sub-batch: 8 frames at the 512x512 configuration's padded size
+// Pixels per sub-batch of the host entries: 16 frames at the 512x512 configuration's padded size (32 at 384 x 384, 4 at 1152 x 1152).
+// Round 4: 8 -> 16.  conv_f43_k's work items are 32 x 32 pixels, so at 8 frames the 160 x 160 layers have 1600 items = 6.25 rounds
+// of the 256 persistent workgroups (a seventh, quarter-filled round: 11 % lost), at 16 frames 12.5; measured 678 -> 698 frames/s
+// at 512 x 512, 1 800 -> 1 939 at 256 x 256 (RRV_SUB_BATCH_FRAMES_640 = 8 / 12 / 16 / 32: 678 / 692 / 698 / 687, the last one
+// too coarse for the copy / kernel overlap of a 64-frame call).
+static long host_sub_pixels() {
+    static const long v = [] { const char* e = getenv("RRV_SUB_BATCH_FRAMES_640"); const long n = e ? atol(e) : 16; return (n < 1 ? 1 : n > 64 ? 64 : n) * 640L * 640L; }();
+    return v;
+}
+#define HOST_SUB_PIXELS host_sub_pixels()
 constexpr int HOST_SETS = 4;
 static int host_sub(int B, int H, int W) {              // frames per sub-batch: small frames are grouped, large ones split finer
     long s = HOST_SUB_PIXELS / ((long)H * W);
