@@ -186,27 +186,46 @@ __global__ __launch_bounds__(256) void conv_last_k(const LastP p) {
     const float bias[3] = {p.bias[0], p.bias[1], p.bias[2]};
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
     const int OH = p.out_H ? p.out_H : p.H, OW = p.out_H ? p.out_W : p.W;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Tile walk.  Workgroup w runs on XCD w % 8 (observed dispatch order; locality only): each XCD gets ONE contiguous band of
+    // the tile list, and the workgroups of an XCD take consecutive tiles of it — horizontally adjacent tiles run on the same
+    // XCD at the same time and the rows above / below a round or two apart, so the 18 x 18 halos (1.27x the tensor) are
+    // fetched from HBM once and hit that XCD's L2 afterwards (round 3's round-robin over the XCDs measured 1.22x).
+    int tile, tile_end, tile_step;
+    if ((gridDim.x & 7) == 0) {
+        const int band = (ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        tile = xcd * band + (blockIdx.x >> 3); tile_step = gridDim.x >> 3;
+        tile_end = (xcd + 1) * band < ntiles ? (xcd + 1) * band : ntiles;
+    } else { tile = blockIdx.x; tile_step = gridDim.x; tile_end = ntiles; }
+    auto origin_of = [&](int tl) {      // 64-bit tile origin (halo pixel (0,0) = ring pixel (y0, x0)); lane offsets are tile-relative and 32-bit
+        const int tx = tl % p.tiles_x, ty = (tl / p.tiles_x) % p.tiles_y, b = tl / (p.tiles_x * p.tiles_y);
+        return p.in + ((size_t)b * (size_t)(p.H + 2) + (ty + p.ty0) * 16) * (size_t)(p.W + 2) * 64 + (size_t)((tx + p.tx0) * 16) * 64 + 4 * kq;
+    };
+    auto halo_off = [&](int g) {
+        int P = 16 * g + t;
+        P = P < 324 ? P : 323;
+        const int hy = P / 18, hx = P - 18 * hy;
+        return (hy * (p.W + 2) + hx) * 64;
+    };
+    f32x4 x[4], xn[4];
+    if (tile < tile_end) {               // the first tile's first group; every later tile's is requested under the previous tile's taps
+        const float* src = origin_of(tile) + halo_off(wave);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = *(const f32x4*)(src + 16 * c);
+    }
+    for (; tile < tile_end; tile += tile_step) {
         const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
         const int y0 = (ty + p.ty0) * 16, x0 = (tx + p.tx0) * 16;
-        // 64-bit tile origin (halo pixel (0,0) = ring pixel (y0, x0)), tile-relative 32-bit lane offsets
-        const float* in_t = p.in + ((size_t)b * (size_t)(p.H + 2) + y0) * (size_t)(p.W + 2) * 64 + (size_t)x0 * 64 + 4 * kq;
+        const float* in_t = origin_of(tile);
+        const bool more = tile + tile_step < tile_end;
+        const float* in_n = more ? origin_of(tile + tile_step) : in_t;
         // ---- G = W . in over the halo: 21 groups of 16 pixels, round-robin over the waves
-        auto halo_off = [&](int g) {
-            int P = 16 * g + t;
-            P = P < 324 ? P : 323;
-            const int hy = P / 18, hx = P - 18 * hy;
-            return (hy * (p.W + 2) + hx) * 64;
-        };
-        f32x4 x[4], xn[4];
-        {
-            const float* src = in_t + halo_off(wave);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) x[c] = *(const f32x4*)(src + 16 * c);
-        }
         for (int g = wave; g < 21; g += 4) {
             if (g + 4 < 21) {                 // next group's pixels while this one is multiplied
                 const float* src = in_t + halo_off(g + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xn[c] = *(const f32x4*)(src + 16 * c);
+            } else if (more) {                // the NEXT tile's first group: its latency lies under this tile's taps and stores
+                const float* src = in_n + halo_off(wave);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) xn[c] = *(const f32x4*)(src + 16 * c);
             }
