@@ -184,3 +184,24 @@ def test_f43_under_the_bounds_checked_debug_mode(pkg, weights, oracle, all_f43_l
 def test_f43_mode_argument_is_checked(hip, pkg):
     with pytest.raises(pkg.RRVError):
         hip.set_f43(3)
+
+
+def test_f43_large_frame_rows_beyond_the_2gib_mark(pkg, weights):
+    """conv_f43_k on a 9216 x 1024 frame (64-channel full-resolution tensors of more than 2 GiB: 64-bit item origins, 32-bit
+    tile-relative offsets, buffer limits clamped at 2 GiB): content that repeats every 64 rows gives bit-identical output
+    rows 64 k apart, also beyond the 2 GiB mark (row 8176 on)."""
+    H, W = 9216, 1024
+    s = pkg.Stylization(weights, cuda=True)
+    s.set_state(load_golden("global_a")["state"])
+    s.set_f43(2)
+    frame = np.tile(pkg.synth_frame(900, 64, W, kind="smooth"), (H // 64, 1, 1))
+    out = s.transfer(frame)
+    assert out.shape == (H, W, 3) and np.isfinite(out).all()
+    top = out[512:576]
+    assert float(top.std()) > 1.0
+    for y0 in (4096, 8192, 8448, 8640):
+        np.testing.assert_array_equal(out[y0:y0 + 64], top)
+    s.set_f43(0)
+    ref = s.transfer(frame)
+    assert not np.array_equal(ref, out) and np.abs(ref - out).max() <= 2 * IMG_ATOL      # the other kernels, the same picture
+    s.close()
