@@ -14,7 +14,10 @@
 //    x all 36 positions = 288 accumulator registers (AGPRs + a few VGPRs), so the input transform is amortised over
 //    two 16-cout blocks: ONE packed VALU op per MFMA;
 //  * 8-channel chunks: v_mfma_f32_16x16x4_f32 twice per (position, cout block); the transformed patch of a lane is
-//    36 x 2 floats (its tile, channel pair 2q, 2q+1) and IS the B operand — it never touches LDS;
+//    36 x 2 floats (its tile, channel pair 2q, 2q+1) and IS the matrix operand — it never touches LDS.  It is the A
+//    operand (U the B operand), so the accumulators are D[tile][cout]: a lane group of 16 ends with the 32 consecutive
+//    output channels of a pixel and the epilogue stores whole 128-byte lines (round 4; with U as the A operand every
+//    lane stored its own 16 bytes and the stores cost 14-23 % of the kernel);
 //  * the four waves of a workgroup share one U block (36 x 32 couts x 8 channels = 36 KB) and one 34 x 34 halo
 //    (40 KB), both double buffered by buffer_load ... lds: 154 KB of LDS, one workgroup per CU;
 //  * a work item = 32 x 32 output pixels x 32 output channels; persistent workgroups walk the items as one stream
@@ -27,7 +30,7 @@
 //
 // F43_ABL (default 0; tools/f43_bench.hip builds one binary per value): microbenchmark switches — 1 no LDS-DMA after the
 // first stage, 2 no K-loop barriers, 4 no stores, 8 no input transform, 16 per-phase clock64 timeline into p.dbg, 32 no
-// epilogue, 64 the two halves of every output line stored back to back (wrong results; what the time between them costs).  The library is compiled with 0: every hook is a discarded constexpr branch.
+// epilogue.  The library is compiled with 0: every hook is a discarded constexpr branch.
 #pragma once
 #include "conv_wino.h"
 
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     const unsigned rawB = lds0 + y0 * G::RAW_ROW_BYTES + tc * 32 + ((q ^ (2 * ((tr & 1) ^ 1))) << 3);
     const unsigned offU = lds0 + 2 * RAW_BYTES + t * 32 + ((q ^ (2 * (t >> 3))) << 3);      // cout row t (block 0); block 1 = +512 (same (row>>3)&1)
 
-    const unsigned lane_off = (unsigned)(((4 * tr) * (p.W + 2) + 4 * tc) * p.Cout + 4 * q) * 4u;      // epilogue stores, see there
+    const unsigned lane_off = (unsigned)(((4 * (q >> 1)) * (p.W + 2) + 16 * (q & 1)) * p.Cout + 2 * t) * 4u;      // epilogue stores, see there
     // Positions whose accumulators live in AGPRs: 28 x 2 blocks x 4 = 224 of the 256; positions 28..35 sit in VGPRs, and the
     // 32 free AGPRs take what the register allocator cannot keep in VGPRs outside the K loops (v_accvgpr moves instead of
     // scratch reloads, whose s_waitcnt vmcnt(0) would serialise the LDS-DMA stream)
@@ -413,10 +416,11 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                 f32x4 (&ac)[2] = *[&]() -> f32x4 (*)[2] { if constexpr (AG) return &accA[pos]; else return &accV[pos - NAG]; }();
                 const f32x2 vv = v[b * 6 + r];
                 f32x2 (&uu)[2] = ur[b & 1][r];
-                if constexpr (FIRST) { mfma_zero<AG>(ac[0], uu[0][0], vv[0]); mfma_zero<AG>(ac[1], uu[1][0], vv[0]); }
-                else { mfma_acc<AG>(ac[0], uu[0][0], vv[0]); mfma_acc<AG>(ac[1], uu[1][0], vv[0]); }
-                mfma_acc<AG>(ac[0], uu[0][1], vv[1]);
-                mfma_acc<AG>(ac[1], uu[1][1], vv[1]);
+                // A operand = the patch (D row = tile), B operand = U (D column = cout row): see the epilogue for why
+                if constexpr (FIRST) { mfma_zero<AG>(ac[0], vv[0], uu[0][0]); mfma_zero<AG>(ac[1], vv[0], uu[1][0]); }
+                else { mfma_acc<AG>(ac[0], vv[0], uu[0][0]); mfma_acc<AG>(ac[1], vv[0], uu[1][0]); }
+                mfma_acc<AG>(ac[0], vv[1], uu[0][1]);
+                mfma_acc<AG>(ac[1], vv[1], uu[1][1]);
             }, std::make_integer_sequence<int, 6>{});
         }, std::make_integer_sequence<int, 6>{});
         // ---- tail: the last patch column, the barrier, the next chunk's first U batch, the transform.  The last chunk of
@@ -487,133 +491,122 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
             continue;
         }
         // ---- output transform Y = A^T M A (rows of M = acc[r*6 + k]) + fused epilogue, all in registers.
-        // A lane ends with the 4 x 4 output pixels of its tile for 4 + 4 + 4 + 4 channels (two cout blocks x two channel pairs),
-        // so the 2 x 2 max pool (E_POOL: the tile holds four whole pooling windows) and the half-resolution residual
-        // (E_RES_UPS: the tile lies over 2 x 2 low-resolution pixels) stay inside the lane.
-        const int yb = e_y0 + 8 * wave + 4 * tr, xb = e_x0 + 4 * tc;
-        // Stores: wave-uniform 64-bit base (SGPRs: image, item origin, the wave's rows, pixel (i, j), cout block) + ONE
-        // loop-invariant 32-bit lane offset (the tile inside the wave's 8 x 32 pixels and the lane's 4 couts): no
+        // The MFMAs ran with the patch as the A operand and U as the B operand, so a lane holds D[tile 4q + e][cout row t]:
+        // FOUR tiles (e = 0..3: row q>>1, columns 4 (q&1) + e of the wave's 2 x 8 tiles) for TWO output channels (cout row t
+        // of both blocks = channels 2t, 2t+1 of the slab, pack_f43_k).  The 16 lanes of a group therefore hold the 32
+        // consecutive channels of one pixel: every store instruction writes four whole 128-byte lines (one per lane group)
+        // instead of 64 separate 16-byte pieces, and the half-resolution residual is read the same way.  The 2 x 2 max pool
+        // (E_POOL: a tile holds four whole pooling windows) and the residual (E_RES_UPS: a tile lies over 2 x 2
+        // low-resolution pixels) stay inside the lane.
+        const int mr = q >> 1, mc0 = 4 * (q & 1);
+        const int yb = e_y0 + 8 * wave + 4 * mr, xb0 = e_x0 + 4 * mc0;
+        // Stores: wave-uniform 64-bit base (SGPRs: image, item origin, the wave's rows, pixel (i, 4e + j)) + ONE
+        // loop-invariant 32-bit lane offset (the lane's first tile inside the wave's 8 x 32 pixels and its channel pair): no
         // per-store address arithmetic in vector registers (precomputed addresses would be held across the whole K loop)
         constexpr bool POOL = (EPI & E_POOL) != 0;
         const int Ho = POOL ? (p.H >> 1) : p.H, Wo = POOL ? (p.W >> 1) : p.W;
         char* const sb = (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout +
                                  ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2) + (POOL ? (e_x0 >> 1) : e_x0) + 1) * p.Cout + e_ntile * 32);
         const int rowb = (Wo + 2) * p.Cout * 4, pixb = p.Cout * 4;
-        const unsigned st_off = POOL ? (unsigned)(((2 * tr) * (Wo + 2) + 2 * tc) * p.Cout + 4 * q) * 4u : lane_off;
+        const unsigned st_off = POOL ? (unsigned)(((2 * mr) * (Wo + 2) + 2 * mc0) * p.Cout + 2 * t) * 4u : lane_off;
         const bool interior = e_y0 + 32 <= p.H && e_x0 + 32 <= p.W;       // wave-uniform: no per-pixel masks inside the image
-        const float* res_b = nullptr;
-        if constexpr ((EPI & E_RES_UPS) != 0) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout + e_ntile * 32 + 4 * q;
-        // Register diet: a 16-cout block is finished in two channel-pair halves — T (6 x 4 pairs) and the first half's 16
-        // output pairs are all that is live besides the next item's V(0) — so nothing spills between the K loops.
+        // the per-channel parameters of the lane's two channels: read from LDS once per item
+        const char* const pl = par + 8 * t;
+        const f32x2 bias = *(const f32x2*)(pl);
+        f32x2 n1m, n1r, n1lo, n1hi, n2m, n2r, n2lo, n2hi, smean, sstd;
+        if constexpr ((EPI & E_NORM1) != 0) { n1m = *(const f32x2*)(pl + 128); n1r = *(const f32x2*)(pl + 256); n1lo = *(const f32x2*)(pl + 384); n1hi = *(const f32x2*)(pl + 512); }
+        if constexpr ((EPI & E_NORM2) != 0) {
+            n2m = *(const f32x2*)(pl + 640); n2r = *(const f32x2*)(pl + 768); n2lo = *(const f32x2*)(pl + 896); n2hi = *(const f32x2*)(pl + 1024);
+            smean = *(const f32x2*)(pl + 1152); sstd = *(const f32x2*)(pl + 1280);
+        }
+        // E_RES_UPS: the 2 x 2 low-resolution residual pixels under each of the four tiles, all requested before the first
+        // store (the counter of outstanding vector-memory operations is in order: a load behind a store waits for the store)
+        f32x2 rres[4][2][2];
+        if constexpr ((EPI & E_RES_UPS) != 0) {
+            const float* const res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout + e_ntile * 32 + 2 * t;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const char* pl = par + (nb * 16 + 4 * q) * 4;
-            f32x4 rres[2][2];    // E_RES_UPS: the 2 x 2 low-resolution residual pixels under the tile (requested now, used ~3000 clocks later)
-            if constexpr ((EPI & E_RES_UPS) != 0) {
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b2 = 0; b2 < 2; ++b2) {
                         // pixels outside the image read the tensor's first pixel instead (valid memory; their outputs are never stored)
-                        const bool in = (yb + 2 * a < p.H) && (xb + 2 * b2 < p.W);
-                        const int pix = in ? (((yb >> 1) + a + 1) * (p.Wr + 2) + (xb >> 1) + b2 + 1) : 0;
-                        rres[a][b2] = *(const f32x4*)(res_b + (size_t)pix * p.Cout + nb * 16);
+                        const bool in = (yb + 2 * a < p.H) && (xb0 + 4 * e + 2 * b2 < p.W);
+                        const int pix = in ? (((yb >> 1) + a + 1) * (p.Wr + 2) + ((xb0 + 4 * e) >> 1) + b2 + 1) : 0;
+                        rres[e][a][b2] = *(const f32x2*)(res_b + (size_t)pix * p.Cout);
                     }
+        }
+        float lrk = 0.2f;
+        asm volatile("" : "+s"(lrk));             // opaque: a literal would be scalarised into two v_mul_f32
+        const f32x2 lrk2 = {lrk, lrk};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {             // tile 4q + e, channels 2t, 2t+1 as one packed pair
+            auto PR = [&](int i) -> f32x2 { return f32x2{ACC(i, 0)[e], ACC(i, 1)[e]}; };
+            f32x2 T[6][4];      // T[r][j] = sum_k M[r][k] A^T[j][k]
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                f43_out(PR(r * 6 + 0), PR(r * 6 + 1), PR(r * 6 + 2), PR(r * 6 + 3), PR(r * 6 + 4), PR(r * 6 + 5), T[r][0], T[r][1], T[r][2], T[r][3]);
+                __builtin_amdgcn_sched_barrier(0);      // accumulators are copied out of the AGPRs row by row, not all up front
             }
-            f32x2 Y0[4][4];      // [i][j]: channels 0, 1 of the lane's four
+            f32x2 pool_prev[2];      // E_POOL: the even column's row-pair maxima, waiting for the odd column
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                auto PR = [&](int i) -> f32x2 { const f32x4 a = ACC(i, nb); return hh ? f32x2{a[2], a[3]} : f32x2{a[0], a[1]}; };
-                f32x2 T[6][4];      // T[r][j] = sum_k M[r][k] A^T[j][k]
+            for (int j = 0; j < 4; ++j) {
+                // The four pixels (i = 0..3) of column j go through the epilogue STAGE by stage: four independent values per
+                // stage (one wave per SIMD: a pixel-by-pixel chain would wait ~9 cycles on every dependent packed op).
+                f32x2 o[4];
+                f43_out(T[0][j], T[1][j], T[2][j], T[3][j], T[4][j], T[5][j], o[0], o[1], o[2], o[3]);
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    f43_out(PR(r * 6 + 0), PR(r * 6 + 1), PR(r * 6 + 2), PR(r * 6 + 3), PR(r * 6 + 4), PR(r * 6 + 5), T[r][0], T[r][1], T[r][2], T[r][3]);
-                    __builtin_amdgcn_sched_barrier(0);      // accumulators are copied out of the AGPRs row by row, not all up front
+                for (int i = 0; i < 4; ++i) o[i] = o[i] + bias;
+                if (EPI & E_RELU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = f32x2{fmaxf(o[i][0], 0.f), fmaxf(o[i][1], 0.f)};
                 }
-                f32x4 pool_prev[2];      // E_POOL: the even column's row-pair maxima, waiting for the odd column
+                if (EPI & E_LRELU) {             // LeakyReLU(0.2): v >= 0 ? v : 0.2 v == max(v, 0.2 v)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x2 Y[4];
-                    f43_out(T[0][j], T[1][j], T[2][j], T[3][j], T[4][j], T[5][j], Y[0], Y[1], Y[2], Y[3]);
-                    if (hh == 0) {
+                    for (int i = 0; i < 4; ++i) { const f32x2 s2 = o[i] * lrk2; o[i] = f32x2{fmaxf(o[i][0], s2[0]), fmaxf(o[i][1], s2[1])}; }
+                }
+                auto norm_clamp = [&](const f32x2 m, const f32x2 r, const f32x2 lo, const f32x2 hi) {      // InstanceNorm.forward with saved statistics: (x - mean) * rstd, clamped
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) Y0[i][j] = Y[i];
-                        continue;
+                    for (int i = 0; i < 4; ++i) o[i] = p2sub(o[i], m) * r;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = f32x2{med3(o[i][0], lo[0], hi[0]), med3(o[i][1], lo[1], hi[1])};
+                };
+                if constexpr ((EPI & E_NORM1) != 0) norm_clamp(n1m, n1r, n1lo, n1hi);
+                if constexpr ((EPI & E_RES_UPS) != 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = o[i] + rres[e][i >> 1][j >> 1];
+                }
+                if constexpr ((EPI & E_NORM2) != 0) {
+                    norm_clamp(n2m, n2r, n2lo, n2hi);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = __builtin_elementwise_fma(o[i], sstd, smean);
+                }
+                if constexpr (POOL) {
+                    f32x2 m2[2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) m2[a] = f32x2{fmaxf(o[2 * a][0], o[2 * a + 1][0]), fmaxf(o[2 * a][1], o[2 * a + 1][1])};
+                    if ((j & 1) == 0) { pool_prev[0] = m2[0]; pool_prev[1] = m2[1]; continue; }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) m2[a] = f32x2{fmaxf(m2[a][0], pool_prev[a][0]), fmaxf(m2[a][1], pool_prev[a][1])};
+                    char* const dst = sb + (2 * e + (j >> 1)) * pixb + st_off;
+                    if (ABL & 4) { if (m2[0][0] == 123.456f) *(float*)dst = m2[0][0] + m2[1][0]; }
+                    else if (interior) {                                     // wave-uniform: the whole item lies inside the image
+                        *(f32x2*)(dst) = m2[0]; *(f32x2*)(dst + rowb) = m2[1];
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+                            if ((yb >> 1) + a < Ho && ((xb0 + 4 * e) >> 1) + (j >> 1) < Wo) *(f32x2*)(dst + a * rowb) = m2[a];
                     }
-                    // The four pixels (i = 0..3) of column j go through the epilogue STAGE by stage: each per-channel parameter
-                    // vector is read from LDS once per column and applied to four independent values (one wave per SIMD: a
-                    // pixel-by-pixel chain would re-read all ten vectors per pixel and wait for LDS ~300 times per item).
-                    f32x4 o4[4];
-                    {
-                        const f32x4 bias = *(const f32x4*)(pl);
+                } else {
+                    char* const dst = sb + (4 * e + j) * pixb + st_off;
+                    if (ABL & 4) { if (o[0][0] == 123.456f) *(float*)dst = o[0][0] + o[1][0] + o[2][0] + o[3][0]; }
+                    else if (interior) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) o4[i] = e4add(f32x4{Y0[i][j][0], Y0[i][j][1], Y[i][0], Y[i][1]}, bias);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (EPI & E_RELU) o4[i] = f4relu(o4[i]);
-                        if (EPI & E_LRELU) o4[i] = f4lrelu(o4[i]);
-                    }
-                    auto norm_clamp4 = [&](const char* q) {      // InstanceNorm.forward with the saved statistics at q: (x - mean) * rstd, clamped
-                        {
-                            const f32x4 m = *(const f32x4*)(q), r = *(const f32x4*)(q + 128);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) o4[i] = e4mul(f4sub(o4[i], m), r);
-                        }
-                        const f32x4 lo = *(const f32x4*)(q + 256), hi = *(const f32x4*)(q + 384);
+                        for (int i = 0; i < 4; ++i) *(f32x2*)(dst + i * rowb) = o[i];
+                    } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o4[i][e] = med3(o4[i][e], lo[e], hi[e]);
-                    };
-                    if (EPI & E_NORM1) norm_clamp4(pl + 128);
-                    if constexpr ((EPI & E_RES_UPS) != 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o4[i] = e4add(o4[i], rres[i >> 1][j >> 1]);
-                    }
-                    if (EPI & E_NORM2) {
-                        norm_clamp4(pl + 640);
-                        const f32x4 sstd = *(const f32x4*)(pl + 1280), smean = *(const f32x4*)(pl + 1152);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o4[i] = e4fma(o4[i], sstd, smean);
-                    }
-                    if constexpr (POOL) {
-                        f32x4 m2[2];
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) m2[a][e] = fmaxf(o4[2 * a][e], o4[2 * a + 1][e]);
-                        if ((j & 1) == 0) { pool_prev[0] = m2[0]; pool_prev[1] = m2[1]; continue; }
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) m2[a][e] = fmaxf(m2[a][e], pool_prev[a][e]);
-                        char* const dst = sb + ((j >> 1) * pixb + nb * 64) + st_off;
-                        if (ABL & 4) { if (m2[0][0] == 123.456f) *(float*)dst = m2[0][0] + m2[1][0]; }
-                        else if (interior) {                                     // wave-uniform: the whole item lies inside the image
-                            *(f32x4*)dst = m2[0]; *(f32x4*)(dst + rowb) = m2[1];
-                        } else {
-#pragma unroll
-                            for (int a = 0; a < 2; ++a)
-                                if ((yb >> 1) + a < Ho && (xb >> 1) + (j >> 1) < Wo) *(f32x4*)(dst + a * rowb) = m2[a];
-                        }
-                    } else {
-                        char* const dst = sb + (j * pixb + nb * 64) + st_off;
-                        if (ABL & 4) { if (o4[0][0] == 123.456f) *(float*)dst = o4[0][0] + o4[1][0] + o4[2][0] + o4[3][0]; }
-                        else if (ABL & 64) {      // microbench only (wrong results): both 64-byte halves of every 128-byte line stored back to back
-                            if (nb == 1) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) { *(f32x4*)(dst + i * rowb - 64) = o4[i]; *(f32x4*)(dst + i * rowb) = o4[i]; }
-                            }
-                        }
-                        else if (interior) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) *(f32x4*)(dst + i * rowb) = o4[i];
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (yb + i < p.H && xb + j < p.W) *(f32x4*)(dst + i * rowb) = o4[i];
-                        }
+                            if (yb + i < p.H && xb0 + 4 * e + j < p.W) *(f32x2*)(dst + i * rowb) = o[i];
                     }
                 }
             }
@@ -642,7 +635,8 @@ __global__ void pack_f43_k(const float* __restrict__ w, float* __restrict__ dst,
         const int chunk = (int)(r % nchunks); r /= nchunks;
         const int n_tile = (int)r;
         const int pair = (fl >> 1) ^ (2 * ((row >> 3) & 1));
-        const int co = n_tile * 32 + row, ci = chunk * 8 + 2 * pair + (fl & 1);
+        // cout row r of block nb (LDS row 16 nb + r) = channel 2 r + nb of the slab: a lane's two accumulator blocks are adjacent channels
+        const int co = n_tile * 32 + 2 * (row & 15) + (row >> 4), ci = chunk * 8 + 2 * pair + (fl & 1);
         const float* g = w + ((size_t)co * Cin + ci) * 9;
         const int pr = pos / 6, pc = pos % 6;
         // U = G g G^T in double, rounded once.  G row j = (1, p_j, p_j^2) / prod_{l != j} (p_j - p_l) for the finite points

@@ -439,7 +439,7 @@ const ConvKey F43_TABLE[] = { FK(E_RELU), FK(E_RELU | E_POOL), FK(E_RELU | E_NOR
 // Does this call run on conv_f43_k?  (Also asked by the callers that choose window alignments.)
 // Mode 1 decides per layer and launch geometry.  A conv_f43_k work item is 32 x 32 pixels x 32 couts — four F(2x2,3x3)
 // items — and takes 4 / base of an F(2x2,3x3) item's time (`base` = the rate ratio on a long item stream: tools/f43_bench.hip
-// at eight 640 x 640 frames per launch with the partially filled last rounds taken out, profiles/r04_f43_bench.txt).  The
+// at sixteen 640 x 640 frames per launch with the partially filled last rounds taken out, profiles/r04_f43_bench.txt).  The
 // 256 persistent workgroups run ceil(items / 256) rounds, so a launch with few items pays for F(4x4,3x3)'s coarser
 // granularity: F(4x4,3x3) runs where rounds23 / (rounds43 x 4 / base) >= 1.04 — from four 640 x 640 frames per launch on
 // every packed layer, from two 1152 x 1152 frames, from one where the items are long (256 channels); never on small
@@ -453,7 +453,7 @@ bool use_f43(rrv_handle h, const ConvW& w, int B, int H, int W, int epi, bool up
     const double slabs = w.Cout / 32;
     const double items43 = (double)((H + 31) / 32) * ((W + 31) / 32) * B * slabs, items23 = (double)((H + 15) / 16) * ((W + 15) / 16) * B * slabs;
     const int ci = w.Cin >= 256 ? 2 : (w.Cin >= 128 ? 1 : 0);
-    static const double BASE_POOL[3] = {1.25, 1.28, 1.35}, BASE_RELU[3] = {1.13, 1.22, 1.26}, BASE_RES[3] = {1.11, 1.19, 1.26};
+    static const double BASE_POOL[3] = {1.20, 1.23, 1.27}, BASE_RELU[3] = {1.18, 1.22, 1.27}, BASE_RES[3] = {1.20, 1.21, 1.26};
     const double base = (epi & E_POOL) ? BASE_POOL[ci] : (epi & E_RES_UPS) ? BASE_RES[ci] : BASE_RELU[ci];
     return rounds(items23) >= 1.04 * rounds(items43) * 4.0 / base;
 }

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/bin
-VARIANTS="0 4 32 33 34 40 41 43 16"     # 4 no stores | 32 no epilogue | +1 no LDS-DMA | +2 no barriers | +8 no input transform | 16 timeline
+VARIANTS="0 4 32 33 34 40 41 43 16 20"     # 4 no stores | 32 no epilogue | +1 no LDS-DMA | +2 no barriers | +8 no input transform | 16 timeline | 20 timeline without stores
 if [ "$1" = build ]; then
     for v in $VARIANTS; do
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DF43_ABL=$v tools/f43_bench.hip -o tools/bin/f43_bench_$v &

@@ -139,5 +139,17 @@ int main() {
     bench<E_RELU>("256->256 @96^2 B22", 22, 96, 96, 256, 256);              // 256x256 frames (384 padded), 22 per sub-batch
     bench<E54>("64->64 @384^2 B22", 22, 384, 384, 64, 64);
     bench<E_RELU>("256->256 @288^2 B2", 2, 288, 288, 256, 256);             // 1024x1024 frames (1152 padded), 2 per sub-batch
+    // the sub-batch of the host entries at 512x512 (16 frames per launch: nothing stays in the memory-side cache between
+    // launches, as in the pipeline).  `base` of use_f43 (rerevst_hip.hip) = the F(2x2) / F(4x4) time ratio of these rows
+    // with the partially filled last round taken out: x ceil(r43) / r43 for the 256-channel rows (12.5 rounds).
+    bench<E_RELU | E_POOL>("64->64 @640^2 B16", 16, 640, 640, 64, 64);
+    bench<E_RELU>("64->128 @320^2 B16", 16, 320, 320, 64, 128);
+    bench<E_RELU | E_POOL>("128->128 @320^2 B16", 16, 320, 320, 128, 128);
+    bench<E_RELU>("128->256 @160^2 B16", 16, 160, 160, 128, 256);
+    bench<E_RELU>("256->256 @160^2 B16", 16, 160, 160, 256, 256);
+    bench<E_RELU | E_POOL>("256->256 @160^2 B16", 16, 160, 160, 256, 256);
+    bench<E54>("256->256 @160^2 B16", 16, 160, 160, 256, 256);
+    bench<E54>("128->128 @320^2 B16", 16, 320, 320, 128, 128);
+    bench<E54>("64->64 @640^2 B16", 16, 640, 640, 64, 64);
     return 0;
 }
