@@ -23,10 +23,14 @@
 //  * a work item = 32 x 32 output pixels x 32 output channels; persistent workgroups walk the items as one stream
 //    (the last two chunks of an item request the next item's first tiles, as in conv_wino_k).
 //
-// LDS images (all ds_read_b64, conflict free in each 32-lane group):
+// LDS images (conflict free in every lane group the LDS serves in one cycle):
 //  raw : [halo row y 0..33][x & 3][x >> 2 (0..8)][32 B = 4 slots of one channel pair]; slot = pair ^ 2*((y>>2)&1):
-//        a read of patch piece (dy, dx) by the 16 tiles (2 x 8) x 2 pairs of a lane group covers 256 distinct bytes
-//  U   : [position 0..35][cout row 0..31][32 B]; slot = pair ^ 2*((row>>3)&1)
+//        a ds_read_b64 of patch piece (dy, dx) by the 16 tiles (2 x 8) x 2 pairs of a 32-lane group covers 256 distinct bytes
+//  U   : [position 0..35][cout row 0..15][4 slots of 16 B = {block 0, block 1} x one channel pair]; slot = pair ^ (-(row>>2) & 3):
+//        ONE ds_read_b128 per position brings a lane the fragments of both cout blocks (six LDS instructions per position
+//        batch instead of twelve ds_read_b64 — every LDS instruction costs the MFMA stream its issue slot); the four
+//        16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...) hold all 16 rows once, rows r, r+4, r+8, r+12 share 16
+//        banks and land in four different slots
 //
 // F43_ABL (default 0; tools/f43_bench.hip builds one binary per value): microbenchmark switches — 1 no LDS-DMA after the
 // first stage, 2 no K-loop barriers, 4 no stores, 8 no input transform, 16 per-phase clock64 timeline into p.dbg, 32 no
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     // rows dy 0..3 have (y>>2)&1 == tr&1 (8 wave is even), rows dy 4,5 the opposite parity
     const unsigned rawA = lds0 + y0 * G::RAW_ROW_BYTES + tc * 32 + ((q ^ (2 * (tr & 1))) << 3);
     const unsigned rawB = lds0 + y0 * G::RAW_ROW_BYTES + tc * 32 + ((q ^ (2 * ((tr & 1) ^ 1))) << 3);
-    const unsigned offU = lds0 + 2 * RAW_BYTES + t * 32 + ((q ^ (2 * (t >> 3))) << 3);      // cout row t (block 0); block 1 = +512 (same (row>>3)&1)
+    const unsigned offU = lds0 + 2 * RAW_BYTES + t * 64 + ((q ^ ((0 - (t >> 2)) & 3)) << 4);      // cout row t of both blocks, channel pair q: one 16-byte slot
 
     const unsigned lane_off = (unsigned)(((4 * (q >> 1)) * (p.W + 2) + 16 * (q & 1)) * p.Cout + 2 * t) * 4u;      // epilogue stores, see there
     // Positions whose accumulators live in AGPRs: 28 x 2 blocks x 4 = 224 of the 256; positions 28..35 sit in VGPRs, and the
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     long long tl[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
     auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
     f32x2 v[NPOS];                // transformed patch B^T d B of the chunk in flight: V[r][k] at index k*6 + r (raw piece (dy, dx) at dx*6 + dy)
-    f32x2 ur[2][6][2];            // U fragments of two position batches: [ring slot][r][cout block]
+    f32x4 ur[2][6];               // U fragments of two position batches: [ring slot][r] = {block 0: channels 2q, 2q+1; block 1: the same}
     auto full_transform = [&](f32x2 (&d)[NPOS]) {
         // column passes: line dx = d[6 dx + 0..5]; then row passes: line r = d[r], d[6 + r], .., d[30 + r]
         f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return d[decltype(nc)::value * 6 + decltype(jc)::value]; });
@@ -358,8 +362,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         constexpr int b = decltype(bc)::value, sl = decltype(slotc)::value;
         static_for([&](auto rc) {
             constexpr int r = decltype(rc)::value;
-            ur[sl][r][0] = lds_rd64<(r * 6 + b) * 1024>(ub);
-            ur[sl][r][1] = lds_rd64<(r * 6 + b) * 1024 + 512>(ub);
+            ur[sl][r] = lds_rd128<(r * 6 + b) * 1024>(ub);
         }, std::make_integer_sequence<int, 6>{});
     };
 
@@ -394,8 +397,8 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
             else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
             if constexpr (b < 5) read_u_batch(ub, std::integral_constant<int, b + 1>{}, std::integral_constant<int, (b + 1) & 1>{});
-            // ---- run b: 24 MFMAs, with ONE mini gap in the middle (a wave may have 15 LDS reads outstanding: the patch column
-            // cannot ride with the 12 U reads) that also carries the chunk's LDS-DMA requests — wave w issues all of its 19 in
+            // ---- run b: 24 MFMAs, with ONE mini gap in the middle for the patch column (issued in the gap, behind the U reads, it
+            // measured 1-2 % slower: profiles/r04_f43_store_study.txt) that also carries the chunk's LDS-DMA requests — wave w issues all of its 19 in
             // run w: the four waves of the CU share one address unit, requests issued at the same time queue behind each other
             static_for([&](auto rc) {
                 constexpr int r = decltype(rc)::value, pos = r * 6 + b;
@@ -415,12 +418,12 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                 constexpr bool AG = pos < NAG;
                 f32x4 (&ac)[2] = *[&]() -> f32x4 (*)[2] { if constexpr (AG) return &accA[pos]; else return &accV[pos - NAG]; }();
                 const f32x2 vv = v[b * 6 + r];
-                f32x2 (&uu)[2] = ur[b & 1][r];
+                const f32x4 uu = ur[b & 1][r];
                 // A operand = the patch (D row = tile), B operand = U (D column = cout row): see the epilogue for why
-                if constexpr (FIRST) { mfma_zero<AG>(ac[0], vv[0], uu[0][0]); mfma_zero<AG>(ac[1], vv[0], uu[1][0]); }
-                else { mfma_acc<AG>(ac[0], vv[0], uu[0][0]); mfma_acc<AG>(ac[1], vv[0], uu[1][0]); }
-                mfma_acc<AG>(ac[0], vv[1], uu[0][1]);
-                mfma_acc<AG>(ac[1], vv[1], uu[1][1]);
+                if constexpr (FIRST) { mfma_zero<AG>(ac[0], vv[0], uu[0]); mfma_zero<AG>(ac[1], vv[0], uu[2]); }
+                else { mfma_acc<AG>(ac[0], vv[0], uu[0]); mfma_acc<AG>(ac[1], vv[0], uu[2]); }
+                mfma_acc<AG>(ac[0], vv[1], uu[1]);
+                mfma_acc<AG>(ac[1], vv[1], uu[3]);
             }, std::make_integer_sequence<int, 6>{});
         }, std::make_integer_sequence<int, 6>{});
         // ---- tail: the last patch column, the barrier, the next chunk's first U batch, the transform.  The last chunk of
@@ -621,22 +624,23 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     }
 }
 
-// Weight transform U = G g G^T for F(4x4,3x3), packed [Cout/32][Cin/8][position 36][cout row 32][8 floats] with the
-// 8-byte slots of a row XOR-swizzled by 2*((row>>3)&1) (a lane-linear LDS-DMA copy lands as the conflict-free image):
+// Weight transform U = G g G^T for F(4x4,3x3), packed [Cout/32][Cin/8][position 36][cout row 16][slot 4][block 2][2 floats] with
+// the 16-byte slots of a row XOR-swizzled by -(row>>2) & 3 (a lane-linear LDS-DMA copy lands as the conflict-free image):
 //   G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
 __global__ void pack_f43_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin) {
     const size_t total = (size_t)Cout * Cin * 36;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
-        const int fl = (int)(r & 7); r >>= 3;             // float inside the 32-byte row: slot = fl >> 1
-        const int row = (int)(r & 31); r >>= 5;
+        const int fl = (int)(r & 3); r >>= 2;             // float inside the 16-byte slot: block fl >> 1, channel fl & 1 of the pair
+        const int slot = (int)(r & 3); r >>= 2;
+        const int row = (int)(r & 15); r >>= 4;
         const int pos = (int)(r % 36); r /= 36;
         const int nchunks = Cin / 8;
         const int chunk = (int)(r % nchunks); r /= nchunks;
         const int n_tile = (int)r;
-        const int pair = (fl >> 1) ^ (2 * ((row >> 3) & 1));
-        // cout row r of block nb (LDS row 16 nb + r) = channel 2 r + nb of the slab: a lane's two accumulator blocks are adjacent channels
-        const int co = n_tile * 32 + 2 * (row & 15) + (row >> 4), ci = chunk * 8 + 2 * pair + (fl & 1);
+        const int pair = slot ^ ((0 - (row >> 2)) & 3);
+        // cout row r of block nb = channel 2 r + nb of the slab: a lane's two accumulator blocks are adjacent channels
+        const int co = n_tile * 32 + 2 * row + (fl >> 1), ci = chunk * 8 + 2 * pair + (fl & 1);
         const float* g = w + ((size_t)co * Cin + ci) * 9;
         const int pr = pos / 6, pc = pos % 6;
         // U = G g G^T in double, rounded once.  G row j = (1, p_j, p_j^2) / prod_{l != j} (p_j - p_l) for the finite points
