@@ -152,7 +152,8 @@ int rrv_transfer_blend(rrv_handle h, const uint8_t* frame_bgr, int H, int W, con
  * 64 px on every side and up to a multiple of 64, cv2.BORDER_REFLECT; :167 crop [64:64+H, 64:64+W]): UNPADDED
  * [B][H][W][3] uint8 frames in, [B][H][W][3] float32 stylized frames out.  The padded frame never exists: the first
  * kernel reads the source through the reflection, the last one writes only the crop window.  Bit-identical to
- * pad -> rrv_transfer_batch -> crop.  _device: HBM buffers, asynchronous; the host form pipelines sub-batches. */
+ * pad -> rrv_transfer_batch -> crop for a fixed kernel choice (rrv_set_f43 mode 0 / 2; in the default mode 1 the choice
+ * follows the launch geometry, and the crop window is one).  _device: HBM buffers, asynchronous; the host form pipelines sub-batches. */
 int rrv_transfer_frames_device(rrv_handle h, const void* d_frames_bgr_u8, int B, int H, int W, void* d_out_bgr_f32);
 int rrv_transfer_frames(rrv_handle h, const uint8_t* frames_bgr, int B, int H, int W, float* out_bgr);
 
@@ -162,6 +163,11 @@ int rrv_transfer_frames(rrv_handle h, const uint8_t* frames_bgr, int B, int H, i
  * rrv_compute == compute_norm :81-83), transfer(feature, style_weight) :94-100 (decoder only, blended state).
  * rrv_release_features frees the cache. */
 int rrv_generate_content_features(rrv_handle h, const uint8_t* frame_bgr, int H, int W, int* feature_id);
+/* The caching pass of a run of frames (test.py:87-101 encodes every frame of the video once) in ONE call: frames_bgr[B][H][W][3],
+ * feature_ids[B] out.  Sub-batches are pipelined inside (copy-in stream + two compute streams, several frames per encoder
+ * launch, the per-frame path's kernel choice — rrv_set_f43), and the encoder's last layer stores straight into the cache
+ * (one arena per call): no allocation, device copy or host wait per frame.  Frames beyond the cache cap are kept as pixels. */
+int rrv_generate_content_features_batch(rrv_handle h, const uint8_t* frames_bgr, int B, int H, int W, int* feature_ids);
 int rrv_add_patch(rrv_handle h, int feature_id);
 int rrv_transfer_features(rrv_handle h, int feature_id, const float* style_weight, int n_styles, float* out_bgr);
 /* n cached features with one weight vector each (style_weight[n][n_styles], out_bgr[n][H][W][3]) in one call — what the
@@ -206,6 +212,9 @@ int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame_bgr, int H, int W
 /* Debug/parity taps: pre-clamp network output (normalised RGB, NHWC [H][W][3]) of the last
  * transfer, copied to host. */
 int rrv_get_preclamp(rrv_handle h, float* out, int H, int W);
+/* The same tap for image `b` of the last launch (a batched entry runs up to 64 frames per launch; for the host-buffer
+ * entries the last launch is the last sub-batch of the call). */
+int rrv_get_preclamp_image(rrv_handle h, float* out, int H, int W, int b);
 
 int rrv_sync(rrv_handle h);
 

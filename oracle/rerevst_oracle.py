@@ -57,21 +57,31 @@ def _mean32(a, **kw):
 # "numpy": nine shifted GEMMs (the default; what the parity tests use).  "torch": the same convolution through
 # torch.nn.functional.conv2d on the CPU — the primitive the reference itself calls (nn.Conv2d -> oneDNN) — used by
 # bench.py's cpu_baseline leg so that the CPU column is timed on the reference's own arithmetic library.
+# "torch64": every convolution ACCUMULATED in float64 and rounded once to float32 (tensors stay float32 between layers, as
+# in the reference).  Two float32 evaluations of this network differ from each other by the sum of their own rounding
+# noise, which Decoder.norm[0] amplifies on near-dead channels (rstd up to 4e3); against this backend a test sees the
+# error of the implementation under test alone.  Used where a full-size comparison would otherwise measure the oracle's
+# float32 summation order as much as the kernel's (tests/test_gpu_default_choice.py, tools/parity_margin.py).
 CONV_BACKEND = "numpy"
 
 
 def set_conv_backend(name):
     global CONV_BACKEND
-    assert name in ("numpy", "torch")
+    assert name in ("numpy", "torch", "torch64")
     CONV_BACKEND = name
 
 
-def _conv3x3_torch(x, w, b):
+def _conv3x3_torch(x, w, b, f64=False):
     import torch
     import torch.nn.functional as TF
     with torch.no_grad():
         t = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
-        y = TF.conv2d(t, torch.from_numpy(np.ascontiguousarray(w)), None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=F32)), padding=1)
+        wt = torch.from_numpy(np.ascontiguousarray(w))
+        bt = None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=F32))
+        if f64:
+            y = TF.conv2d(t.double(), wt.double(), None if bt is None else bt.double(), padding=1).float()
+        else:
+            y = TF.conv2d(t, wt, bt, padding=1)
         return np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy())
 
 
@@ -79,8 +89,8 @@ def conv3x3(x, w, b=None):
     """Zero-pad-1, stride-1 3x3 convolution.  x [B,H,W,Cin] f32, w OIHW [Cout,Cin,3,3].
     (nn.Conv2d(kernel_size=3, padding=1): style_network_global.py:103-104,145,182,186,341;
     vgg19.features convs.)  Evaluated as nine shifted [B*H*W,Cin]x[Cin,Cout] products."""
-    if CONV_BACKEND == "torch":
-        return _conv3x3_torch(x, w, b)
+    if CONV_BACKEND in ("torch", "torch64"):
+        return _conv3x3_torch(x, w, b, CONV_BACKEND == "torch64")
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     xp = np.zeros((B, H + 2, W + 2, Cin), dtype=F32)
@@ -105,6 +115,8 @@ def conv1x1(x, w):
     """Bias-free 1x1 convolution, w [Cout,Cin,1,1] (conv_shortcut :105) or [Cout,Cin]."""
     B, H, W, Cin = x.shape
     w2 = w.reshape(w.shape[0], Cin)
+    if CONV_BACKEND == "torch64":
+        return (x.reshape(-1, Cin).astype(F64) @ np.ascontiguousarray(w2.T).astype(F64)).astype(F32).reshape(B, H, W, -1)
     return (x.reshape(-1, Cin) @ np.ascontiguousarray(w2.T)).reshape(B, H, W, -1)
 
 

@@ -44,6 +44,7 @@ SYMBOLS = {
     "rrv_transfer_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rrv_transfer_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rrv_generate_content_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rrv_generate_content_features_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rrv_add_patch": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_transfer_features": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "rrv_transfer_features_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
@@ -54,6 +55,7 @@ SYMBOLS = {
     "rrv_feature_cache_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "rrv_transfer_frame_mode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rrv_get_preclamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "rrv_get_preclamp_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rrv_sync": (C.c_int, [C.c_void_p]),
     "rrv_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "rrv_set_host_io": (C.c_int, [C.c_void_p, C.c_int]),

@@ -41,6 +41,17 @@
 #ifndef F43_ABL
 #define F43_ABL 0
 #endif
+// F43_DMA: where a wave issues the 19 LDS-DMA requests of a chunk (tools/f43_bench.hip builds one binary per value;
+// profiles/r05_f43_timeline.txt): 0 all in the mini gap of run `wave` | 1 one per position step from step 0, all waves together |
+// 2 two per step, wave w in steps 5w..5w+9 | 3 one per step, wave w from step 4w.
+#ifndef F43_DMA
+#define F43_DMA 1
+#endif
+// F43_TAIL: 0 barrier, first U batch, whole input transform | 1 column passes of the transform BEFORE the barrier (they need
+// nothing the barrier guards and absorb the waves' skew), row passes behind the first U batch's reads
+#ifndef F43_TAIL
+#define F43_TAIL 0
+#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -402,9 +413,30 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
             // run w: the four waves of the CU share one address unit, requests issued at the same time queue behind each other
             static_for([&](auto rc) {
                 constexpr int r = decltype(rc)::value, pos = r * 6 + b;
+                constexpr int step = b * 6 + r;                  // issue order of the 36 position steps of a chunk
+                auto dma_req = [&](auto nc) {                    // request n of the chunk: 0..9 the halo, 10..18 the U block
+                    constexpr int n = decltype(nc)::value;
+                    if constexpr (n < G::RAW_IT) bufld16_rs(rs_r, rdst + (n * NT + wave * 64) * 16, asrc[n], rsoff);
+                    else if constexpr (n < G::RAW_IT + G::U_IT) bufld16_rs(rs_u, udst + ((n - G::RAW_IT) * NT + wave * 64) * 16, tid * 16, usoff + (n - G::RAW_IT) * NT * 16);
+                };
+                if constexpr (F43_DMA == 1) {
+                    if constexpr (step < G::RAW_IT + G::U_IT) { if (!(ABL & 1)) dma_req(std::integral_constant<int, step>{}); }
+                } else if constexpr (F43_DMA == 2) {
+                    static_for([&](auto wc) {
+                        constexpr int k = step - 5 * decltype(wc)::value;
+                        if constexpr (k >= 0 && k < 10) {
+                            if (!(ABL & 1) && wave == decltype(wc)::value) { dma_req(std::integral_constant<int, 2 * k>{}); dma_req(std::integral_constant<int, 2 * k + 1>{}); }
+                        }
+                    }, std::make_integer_sequence<int, 4>{});
+                } else if constexpr (F43_DMA == 3) {
+                    static_for([&](auto wc) {
+                        constexpr int n = step - 4 * decltype(wc)::value;
+                        if constexpr (n >= 0 && n < G::RAW_IT + G::U_IT) { if (!(ABL & 1) && wave == decltype(wc)::value) dma_req(std::integral_constant<int, n>{}); }
+                    }, std::make_integer_sequence<int, 4>{});
+                }
                 if constexpr (r == 3) {
                     if constexpr (b >= 1) { if (!last) read_patch_col(RBt{}, std::integral_constant<int, b - 1>{}); }
-                    if constexpr (b < 4) {
+                    if constexpr (b < 4 && F43_DMA == 0) {
                         if (!(ABL & 1) && wave == b) {
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -431,12 +463,23 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         // registers), see the item loop.
         if (!last) read_patch_col(RBt{}, std::integral_constant<int, 5>{});
         tick(1);
+        if constexpr (F43_TAIL == 1) {
+            if (!last && !(ABL & 8)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return v[decltype(nc)::value * 6 + decltype(jc)::value]; });
+            }
+            tick(5);
+        }
         if (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         tick(3);
         if (!last) {
             read_u_batch(ubn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-            if (!(ABL & 8)) full_transform(v);
+            if constexpr (F43_TAIL == 1) {
+                if (!(ABL & 8)) f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return v[decltype(jc)::value * 6 + decltype(nc)::value]; });
+            } else {
+                if (!(ABL & 8)) full_transform(v);
+            }
         }
         tick(5);
     };

@@ -143,8 +143,9 @@ struct rrv_ctx {
     // cached raw relu4_1 feature of one (padded) frame, H x W = frame size.  Beyond feat_cap (rrv_set_feature_cache_cap)
     // a frame is kept as its uint8 pixels instead (u8, ~10x smaller) and re-encoded when it is used: the reference's
     // cache is on disk and unbounded (test.py:87-101), this one degrades to "encode + decode per frame" instead of failing
-    struct Feature { float* p; int H, W; uint8_t* u8; };
+    struct Feature { float* p; int H, W; uint8_t* u8; bool owned = true; };      // owned: its own allocation; else it lives in one of feat_blocks
     std::vector<Feature> features;
+    std::vector<void*> feat_blocks;            // arenas of rrv_generate_content_features_batch (one allocation per call, features back to back)
     size_t feat_cap = (size_t)64 << 30, feat_bytes = 0;
     std::vector<float*> patches;               // relu4_1 features of added frames (ring layout images)
     int patch_h = 0, patch_w = 0, add_H = 0, add_W = 0;
@@ -161,7 +162,7 @@ struct rrv_ctx {
     // frames handed to rrv_add wait here (uint8, HBM) and are encoded together, 8 per encoder launch, when their
     // features are first needed (rrv_compute): the encoder at B = 1 runs at a fraction of its batched rate
     uint8_t* pend_u8 = nullptr; size_t pend_cap = 0; int pend_n = 0;
-    const float* last_pre = nullptr; int last_pre_H = 0, last_pre_W = 0;   // where rrv_get_preclamp finds the last tap
+    const float* last_pre = nullptr; int last_pre_H = 0, last_pre_W = 0, last_pre_B = 0;   // where rrv_get_preclamp finds the last tap
     // host-buffer entry: two staging sets (pinned host + device, input and output) so that H2D / kernels / D2H /
     // the copies from and to the caller's pageable arrays of consecutive sub-batches overlap
     // Four sets and two dedicated copy streams: the compute streams never wait behind a DMA of their own stream.
@@ -436,6 +437,17 @@ const ConvKey WINO_TABLE[] = {
 
 const ConvKey F43_TABLE[] = { FK(E_RELU), FK(E_RELU | E_POOL), FK(E_RELU | E_NORM1), FK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2) };
 
+// Persistent workgroups of a transform-domain launch: `occ` per CU, on the 1/grid_share of the CUs this launch may use
+// (rrv_set_grid_share, look-ahead tickets: whole XCD rows, never empty).  conv() sizes its grid with it and use_f43 its rounds.
+unsigned resident_wgs(rrv_handle h, int occ) {
+    unsigned r = (unsigned)h->n_cus * (unsigned)occ;
+    if (h->grid_share > 1) {
+        r = (r / h->grid_share) & ~7u;      // (a small / partitioned / CU-masked device: n_cus * occ / share < 8)
+        if (r < 8) r = 8;
+    }
+    return r;
+}
+
 // Does this call run on conv_f43_k?  (Also asked by the callers that choose window alignments.)
 // Mode 1 decides per layer and launch geometry.  A conv_f43_k work item is 32 x 32 pixels x 32 couts — four F(2x2,3x3)
 // items — and takes 4 / base of an F(2x2,3x3) item's time (`base` = the rate ratio on a long item stream: tools/f43_bench.hip
@@ -448,7 +460,7 @@ const ConvKey F43_TABLE[] = { FK(E_RELU), FK(E_RELU | E_POOL), FK(E_RELU | E_NOR
 bool use_f43(rrv_handle h, const ConvW& w, int B, int H, int W, int epi, bool ups, int ksplit, bool per_image) {
     if (!h->f43_path || !w.pk_f43 || !((h->f43_layers >> w.f43_bit) & 1u) || ups || ksplit > 1 || per_image || h->f43_mode == 0) return false;
     if (h->f43_mode == 2) return true;
-    const double R = 256.0;      // persistent workgroups of a full-chip launch (MI355X: one per CU)
+    const double R = (double)resident_wgs(h, 1);      // persistent workgroups of this launch: one per CU the handle may use (rrv_create: device CU count under HSA_CU_MASK / RRV_CUS; rrv_set_grid_share / look-ahead tickets: a share of them)
     auto rounds = [&](double items) { return std::ceil(items / R); };
     const double slabs = w.Cout / 32;
     const double items43 = (double)((H + 31) / 32) * ((W + 31) / 32) * B * slabs, items23 = (double)((H + 15) / 16) * ((W + 15) / 16) * B * slabs;
@@ -523,11 +535,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (wino) {   // persistent workgroups (one per CU; two for the upsample-fused form), walking tiles_x*tiles_y*B*(Cout/32) work items
         const unsigned slabs = (unsigned)(w.Cout / 32) * ks;
         const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B) * slabs;
-        unsigned resident = (unsigned)h->n_cus * (c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);
-        if (h->grid_share > 1) {      // rrv_set_grid_share: leave CUs to the launches of the other stream(s); whole XCD rows, never empty
-            resident = (resident / h->grid_share) & ~7u;      // (a small / partitioned / CU-masked device: n_cus * OCC / share < 8)
-            if (resident < 8) resident = 8;
-        }
+        const unsigned resident = resident_wgs(h, c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);      // rrv_set_grid_share leaves CUs to the launches of the other stream(s)
         grid = dim3(items < resident ? items : resident, 1);
         // slabs of one pixel tile on one XCD (workgroup w runs on XCD w % 8): the raw tile is fetched once per XCD group
         p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
@@ -768,7 +776,8 @@ Plan& pick_plan(rrv_handle h, Plan (&v)[2], int B, int H, int W) {
 struct PadCrop { int src_H, src_W, top, left; };
 
 // nb: images to encode (plans are grow-only, so a plan may hold room for more)
-int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0, const PadCrop* pc, int nb) {
+// out41 != nullptr: the relu4_1 tensor is written THERE ([nb] ring-layout images, zero ring) instead of the plan's c41 (feature cache)
+int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const float* norm0, const PadCrop* pc, int nb, Tens* out41 = nullptr) {
     const int H = e.H, W = e.W, B = nb;
     if (nb < 1 || nb > e.B) return fail(h, RRV_E_ARG, "run_encoder: batch does not fit the plan");
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "image too large ((H+2)*(W+2)*64 must be < 2^31)");
@@ -791,7 +800,7 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
     c = ConvCall{&e.c31, &e.c32, W_(5), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
     c = ConvCall{&e.c32, &e.c33, W_(6), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
     c = ConvCall{&e.c33, &e.p3, W_(7), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
-    c = ConvCall{&e.p3, &e.c41, W_(8), e.p3.H, e.p3.W}; c.B = B; c.epi = E_RELU | (norm0 ? E_NORM1 : 0); c.n1 = norm0; RCHK(conv(h, c));
+    c = ConvCall{&e.p3, out41 ? out41 : &e.c41, W_(8), e.p3.H, e.p3.W}; c.B = B; c.epi = E_RELU | (norm0 ? E_NORM1 : 0); c.n1 = norm0; RCHK(conv(h, c));
     return RRV_OK;
 }
 
@@ -896,7 +905,7 @@ int run_last(rrv_handle h, const Tens& o2, int B, int H, int W, float* d_out, fl
     LastP lp{o2.p, H, W, B, h->last_w, h->last_b, d_out, pre, (W + 15) / 16, (H + 15) / 16,
              pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0, 0, 0};
     if (wl) { lp.ty0 = wl->y0 / 16; lp.tx0 = wl->x0 / 16; lp.tiles_y = (wl->y1 - wl->y0) / 16; lp.tiles_x = (wl->x1 - wl->x0) / 16; }
-    h->last_pre = pre; h->last_pre_H = H; h->last_pre_W = W;
+    h->last_pre = pre; h->last_pre_H = H; h->last_pre_W = W; h->last_pre_B = B;
     return launch(h, "conv_last", 2.0 * B * H * W * 576 * 3, (256.0 + 12.0) * B * H * W, [&] {
         const unsigned tiles = (unsigned)(lp.tiles_x * lp.tiles_y * B), resident = (unsigned)h->n_cus * 4;     // persistent: 4 workgroups of 35 KB per CU
         hipLaunchKernelGGL(conv_last_k, dim3(tiles < resident ? tiles : resident), dim3(256), 0, h->stream, lp);
@@ -1363,6 +1372,40 @@ int compute_style_streaming(rrv_handle h, int sid, int G) {
 // =============================================================================================
 extern "C" {
 
+// CUs that HSA_CU_MASK ("<gpu ids>:<cu ranges>[;...]", e.g. "0:0-127" or "0,1:0-31,64-95") leaves to `device`; 0 = not masked.
+static int cu_mask_count(const char* env, int device, int n_cus) {
+    if (!env || !*env) return 0;
+    auto parse_list = [](const char* b, const char* e, int limit, std::vector<char>& hit) {     // "a-b,c" -> hit[]
+        hit.assign((size_t)limit, 0);
+        while (b < e) {
+            char* q = nullptr;
+            long lo = strtol(b, &q, 10), hi = lo;
+            if (q == b) return false;
+            if (q < e && *q == '-') { const char* r = q + 1; hi = strtol(r, &q, 10); if (q == r) return false; }
+            for (long v = lo; v <= hi; ++v) if (v >= 0 && v < limit) hit[(size_t)v] = 1;
+            b = (q < e && *q == ',') ? q + 1 : q;
+            if (b < e && q == b) return false;
+        }
+        return true;
+    };
+    const char* p = env;
+    while (*p) {
+        const char* semi = strchr(p, ';');
+        const char* end = semi ? semi : p + strlen(p);
+        const char* colon = (const char*)memchr(p, ':', (size_t)(end - p));
+        if (colon) {
+            std::vector<char> gpus, cus;
+            if (parse_list(p, colon, 64, gpus) && device < 64 && gpus[(size_t)device] && parse_list(colon + 1, end, n_cus, cus)) {
+                int n = 0;
+                for (char c : cus) n += c;
+                return n;
+            }
+        }
+        p = semi ? semi + 1 : end;
+    }
+    return 0;
+}
+
 int rrv_create(int device, rrv_handle* out) {
     if (!out) return RRV_E_ARG;
     *out = nullptr;
@@ -1393,6 +1436,11 @@ int rrv_create(int device, rrv_handle* out) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
+        // The runtime reports the physical CU count also when HSA_CU_MASK leaves this process fewer: persistent grids and the
+        // rounds arithmetic of use_f43 follow the CUs the process can actually run on (RRV_CUS overrides both).
+        const int masked = cu_mask_count(getenv("HSA_CU_MASK"), device, h->n_cus);
+        if (masked > 0 && masked < h->n_cus) h->n_cus = masked;
+        if (const char* e = getenv("RRV_CUS")) { const int n = atoi(e); if (n >= 1 && n <= 1024) h->n_cus = n; }
     }
     if (const char* e = getenv("RRV_F43_LAYERS")) h->f43_layers = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("RRV_F43")) h->f43_mode = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
@@ -1474,7 +1522,8 @@ int rrv_destroy(rrv_handle h) {
     for (int i = 0; i < 6; ++i) { if (h->fc_w[i]) (void)hipFree(h->fc_w[i]); if (h->fc_b[i]) (void)hipFree(h->fc_b[i]); }
     if (h->fold_tmp) (void)hipFree(h->fold_tmp);
     for (float* p : h->patches) (void)hipFree(p);
-    for (auto& f : h->features) { if (f.p) (void)hipFree(f.p); if (f.u8) (void)hipFree(f.u8); }
+    for (auto& f : h->features) if (f.owned) { if (f.p) (void)hipFree(f.p); if (f.u8) (void)hipFree(f.u8); }
+    for (void* b : h->feat_blocks) (void)hipFree(b);
     free_plans(h);
     for (StyleState& s : h->styles) { if (s.blob) (void)hipFree(s.blob); if (s.smean) (void)hipFree(s.smean); tfree(&s.map); }
     if (h->d_u8) (void)hipFree(h->d_u8);
@@ -2199,7 +2248,7 @@ int rrv_generate_content_features(rrv_handle h, const uint8_t* frame, int H, int
     if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "generate_content_features: frame too small");
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
-    rrv_ctx::Feature ft{nullptr, H, W, nullptr};
+    rrv_ctx::Feature ft{nullptr, H, W, nullptr, true};
     const size_t need = feature_floats(H, W) * sizeof(float);
     if (h->feat_bytes + need > h->feat_cap) {        // over the cap: keep the pixels, encode on use
         RCHK(dmalloc(h, (void**)&ft.u8, (size_t)H * W * 3));
@@ -2220,6 +2269,97 @@ int rrv_generate_content_features(rrv_handle h, const uint8_t* frame, int H, int
     h->features.push_back(ft);
     *feature_id = (int)h->features.size() - 1;
     return RRV_OK;
+}
+
+// The caching pass of a whole run of frames ("Multi-style Interpolation/test.py":87-101 encodes every frame once, one at a
+// time, and writes cache/%d.pt): B equally sized frames in ONE call.  Sub-batches (as in host_pipeline: ~6.6 Mpixel) alternate
+// over the two compute streams while the copy-in stream brings the next ones; the encoder runs several frames per launch
+// with the per-frame path's kernel choice (use_f43), and its last layer stores straight into the cache — one arena per call,
+// features back to back in ring layout, zeroed once — so there is no allocation, device copy or host wait per frame.
+// Frames beyond the cache cap are kept as pixels (one block), as rrv_generate_content_features does.
+int rrv_generate_content_features_batch(rrv_handle h, const uint8_t* frames, int B, int H, int W, int* feature_ids) {
+    if (!h || !frames || !feature_ids || B < 1) return RRV_E_ARG;
+    if (!h->finalized) return fail(h, RRV_E_WEIGHTS, "weights not finalized");
+    if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "generate_content_features: frame too small");
+    if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "generate_content_features: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
+    HIPCHK(hipSetDevice(h->dev));
+    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));
+    RCHK(sync_all(h));
+    const size_t fb = (size_t)H * W * 3;
+    Tens one; one.B = 1; one.H = H / 8; one.W = W / 8; one.C = 512;
+    const size_t img = one.img_floats(), slack = feature_floats(H, W) - img;
+    // how many fit the cache (the arena of n features holds n images + one slack)
+    int n_res = 0;
+    while (n_res < B && h->feat_bytes + ((size_t)(n_res + 1) * img + slack) * sizeof(float) <= h->feat_cap) ++n_res;
+    const int id0 = (int)h->features.size();
+    float* arena = nullptr;
+    if (n_res) {
+        RCHK(dmalloc(h, (void**)&arena, ((size_t)n_res * img + slack) * sizeof(float)));
+        h->feat_blocks.push_back(arena);
+        HIPCHK(hipMemsetAsync(arena, 0, ((size_t)n_res * img + slack) * sizeof(float), h->streams[0]));      // the zero ring of every feature
+        HIPCHK(hipStreamSynchronize(h->streams[0]));
+        h->feat_bytes += ((size_t)n_res * img + slack) * sizeof(float);
+        for (int i = 0; i < n_res; ++i) h->features.push_back(rrv_ctx::Feature{arena + (size_t)i * img, H, W, nullptr, false});
+    }
+    if (n_res < B) {       // over the cap: pixels only
+        uint8_t* blk = nullptr;
+        RCHK(dmalloc(h, (void**)&blk, (size_t)(B - n_res) * fb));
+        h->feat_blocks.push_back(blk);
+        HIPCHK(hipMemcpy(blk, frames + (size_t)n_res * fb, (size_t)(B - n_res) * fb, hipMemcpyHostToDevice));
+        for (int i = n_res; i < B; ++i) h->features.push_back(rrv_ctx::Feature{nullptr, H, W, blk + (size_t)(i - n_res) * fb, false});
+    }
+    for (int i = 0; i < B; ++i) feature_ids[i] = id0 + i;
+    if (!n_res) return RRV_OK;
+    const int sub = host_sub(n_res, H, W);
+    const int nchunk = (n_res + sub - 1) / sub;
+    const int nsets = nchunk < HOST_SETS ? nchunk : HOST_SETS;
+    const bool in_pin = is_pinned(frames, (size_t)n_res * fb);
+    for (int i = 0; i < nsets; ++i) {
+        auto& st = h->hstage[i];
+        if (st.cap < (size_t)sub * fb) {
+            if (st.d_in) (void)hipFree(st.d_in);
+            if (st.d_out) (void)hipFree(st.d_out);
+            st.d_in = nullptr; st.d_out = nullptr; st.cap = 0;
+            RCHK(dmalloc(h, (void**)&st.d_in, (size_t)sub * fb));
+            RCHK(dmalloc(h, (void**)&st.d_out, (size_t)sub * fb * sizeof(float)));      // (the staging sets keep host_pipeline's invariant: output = 4 x the input bytes)
+            st.cap = (size_t)sub * fb;
+        }
+        if (!in_pin && st.pcap < (size_t)sub * fb) {
+            if (st.pin_in) (void)hipHostFree(st.pin_in);
+            if (st.pin_out) (void)hipHostFree(st.pin_out);
+            st.pin_in = nullptr; st.pin_out = nullptr; st.pcap = 0;
+            HIPCHK(hipHostMalloc((void**)&st.pin_in, (size_t)sub * fb, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&st.pin_out, (size_t)sub * fb * sizeof(float), hipHostMallocDefault));
+            st.pcap = (size_t)sub * fb;
+        }
+    }
+    struct Restore { rrv_handle h; ~Restore() { h->stream = h->streams[0]; h->f43_path = false; h->next_slot = 0; } } restore{h};
+    const int nstreams = (h->profiling || h->n_slots < 2) ? 1 : 2;
+    int rc = RRV_OK;
+    for (int k = 0; k < nchunk && rc == RRV_OK; ++k) {
+        auto& st = h->hstage[k % HOST_SETS];
+        const int nb = (k + 1) * sub <= n_res ? sub : n_res - k * sub;
+        const uint8_t* src = frames + (size_t)k * sub * fb;
+        if (k >= HOST_SETS) HIPCHK(hipEventSynchronize(st.k_done));            // the encoder of k-4 has read this set's input (also frees pin_in)
+        if (!in_pin) { host_copy(st.pin_in, src, (size_t)nb * fb); src = st.pin_in; }
+        const int slot = k % nstreams;
+        HIPCHK(hipMemcpyAsync(st.d_in, src, (size_t)nb * fb, hipMemcpyHostToDevice, h->copy_in));
+        HIPCHK(hipEventRecord(st.in_done, h->copy_in));
+        HIPCHK(hipStreamWaitEvent(h->streams[slot], st.in_done, 0));
+        h->stream = h->streams[slot];
+        h->f43_path = true;                  // the same kernel choice as the per-frame path's encoder (rrv_set_f43)
+        EncPlan& e = pick_plan(h, h->enc_frame[slot], nb, H, W);
+        rc = enc_plan(h, e, nb, H, W);
+        if (rc != RRV_OK) break;
+        Tens out41 = one; out41.B = nb; out41.p = arena + (size_t)k * sub * img;
+        rc = run_encoder(h, e, st.d_in, 0, nullptr, nullptr, nb, &out41);
+        if (rc != RRV_OK) break;
+        HIPCHK(hipEventRecord(st.k_done, h->streams[slot]));
+    }
+    const int rs = sync_all(h);
+    if (rc == RRV_OK) rc = rs;
+    if (rc == RRV_OK && h->debug) rc = debug_verify(h, "generate_content_features_batch");
+    return rc;
 }
 
 int rrv_set_feature_cache_cap(rrv_handle h, size_t bytes) {
@@ -2393,7 +2533,9 @@ int rrv_release_features(rrv_handle h) {
     if (!h) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
-    for (auto& f : h->features) { if (f.p) (void)hipFree(f.p); if (f.u8) (void)hipFree(f.u8); }
+    for (auto& f : h->features) if (f.owned) { if (f.p) (void)hipFree(f.p); if (f.u8) (void)hipFree(f.u8); }
+    for (void* b : h->feat_blocks) (void)hipFree(b);
+    h->feat_blocks.clear();
     h->features.clear();
     h->feat_bytes = 0;
     return RRV_OK;
@@ -2421,14 +2563,17 @@ int rrv_transfer_frame_mode(rrv_handle h, const uint8_t* frame, int H, int W, fl
     return RRV_OK;
 }
 
-int rrv_get_preclamp(rrv_handle h, float* out, int H, int W) {
+int rrv_get_preclamp_image(rrv_handle h, float* out, int H, int W, int b) {
     if (!h || !out) return RRV_E_ARG;
     if (!h->last_pre || h->last_pre_H != H || h->last_pre_W != W) return fail(h, RRV_E_STATE, "get_preclamp: no transfer of that size yet");
+    if (b < 0 || b >= h->last_pre_B) return fail(h, RRV_E_ARG, "get_preclamp: the last launch had fewer images");
     HIPCHK(hipSetDevice(h->dev));
     RCHK(sync_all(h));
-    HIPCHK(hipMemcpy(out, h->last_pre, (size_t)H * W * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, h->last_pre + (size_t)b * H * W * 3, (size_t)H * W * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return RRV_OK;
 }
+
+int rrv_get_preclamp(rrv_handle h, float* out, int H, int W) { return rrv_get_preclamp_image(h, out, H, W, 0); }
 
 int rrv_sync(rrv_handle h) {
     if (!h) return RRV_E_ARG;

@@ -36,6 +36,13 @@ def read_image_bgr(path):
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
+def image_size(path):
+    """(H, W) from the file's header, without decoding the pixels."""
+    with _pil().open(path) as im:
+        w, h = im.size
+    return h, w
+
+
 def to_uint8(img):
     """cv2.imwrite's conversion of a float image: round to nearest, saturate to 0..255."""
     if img.dtype == np.uint8:
@@ -208,23 +215,35 @@ def stylize_files(model, style_path, frame_paths, out_dir, video_path=None, fps=
             write_image_bgr(path, u8)
             return (_encode_jpeg(u8, 95), u8.shape) if inline_video else None
 
-        first = read_image_bgr(frame_paths[lo]) if hi > lo else None
         on_device = getattr(model, "transfer_frames", None)      # absent on a model with the reference's surface only
-        fast = on_device is not None and use_global and first is not None
+        fast = on_device is not None and use_global and hi > lo
         gpu_s = 0.0
         if fast:
-            H, W = first.shape[:2]
+            # The reference reshapes every frame on its own (generate_real_video.py:152-171) and so accepts a list of mixed
+            # sizes; the batched entry needs equal sizes per call.  The headers are read up front (no decode) and the chunks
+            # are cut from RUNS of equally sized frames: a uniform video is one run, a mixed list degrades to shorter chunks.
+            sizes = list(pool.map(image_size, frame_paths[lo:hi]))          # (H, W) per frame of this shard
             pkg_empty = getattr(importlib.import_module("rerevst-code_amd"), "pinned_empty", None)
             nbuf = 3
             chunk = max(1, min(int(chunk), hi - lo))
-            in_bufs = [_host_buffer(pkg_empty, (chunk, H, W, 3), np.uint8) for _ in range(nbuf)]
-            out_bufs = [_host_buffer(pkg_empty, (chunk, H, W, 3), np.float32) for _ in range(nbuf)]
-            chunks = [list(range(c0, min(hi, c0 + chunk))) for c0 in range(lo, hi, chunk)]
+            chunks = []
+            for i in range(lo, hi):
+                if chunks and len(chunks[-1]) < chunk and sizes[chunks[-1][0] - lo] == sizes[i - lo]:
+                    chunks[-1].append(i)
+                else:
+                    chunks.append([i])
+            biggest = max(h * w for h, w in sizes)
+            in_flat = [_host_buffer(pkg_empty, (chunk * biggest * 3,), np.uint8) for _ in range(nbuf)]
+            out_flat = [_host_buffer(pkg_empty, (chunk * biggest * 3,), np.float32) for _ in range(nbuf)]
+
+            def views(k):                        # chunk k's input / output slots: [frames][H][W][3] views of buffer set k % nbuf
+                (H, W), m = sizes[chunks[k][0] - lo], len(chunks[k])
+                return in_flat[k % nbuf][:m * H * W * 3].reshape(m, H, W, 3), out_flat[k % nbuf][:m * H * W * 3].reshape(m, H, W, 3)
 
             def load(path, dst):                 # worker: decode straight into the page-locked input slot
                 img = read_image_bgr(path)
                 if img.shape != dst.shape:
-                    raise ValueError("frame %s is %r, the video's first frame %r (transfer_frames needs equal sizes)" % (path, img.shape, dst.shape))
+                    raise ValueError("frame %s decodes to %r, its header said %r" % (path, img.shape, dst.shape))
                 dst[...] = img
 
             dec = {}                             # chunk -> decode futures
@@ -232,7 +251,8 @@ def stylize_files(model, style_path, frame_paths, out_dir, video_path=None, fps=
 
             def submit_decode(k):
                 if k < len(chunks) and k not in dec:
-                    dec[k] = [pool.submit(load, frame_paths[i], in_bufs[k % nbuf][j]) for j, i in enumerate(chunks[k])]
+                    dst = views(k)[0]
+                    dec[k] = [pool.submit(load, frame_paths[i], dst[j]) for j, i in enumerate(chunks[k])]
             submit_decode(0); submit_decode(1)
             for k, idx in enumerate(chunks):
                 for f in dec.pop(k):
@@ -240,7 +260,8 @@ def stylize_files(model, style_path, frame_paths, out_dir, video_path=None, fps=
                 for f in enc[k % nbuf]:          # the encoders of chunk k-3 have left this output buffer
                     f.result()
                 t0 = time.perf_counter()
-                styled = on_device(in_bufs[k % nbuf][:len(idx)], out=out_bufs[k % nbuf][:len(idx)])
+                src, dst = views(k)
+                styled = on_device(src, out=dst)
                 gpu_s += time.perf_counter() - t0
                 submit_decode(k + 2)             # its input buffer was chunk k-1's: consumed
                 futs = []
@@ -257,8 +278,7 @@ def stylize_files(model, style_path, frame_paths, out_dir, video_path=None, fps=
                 for f in fl:
                     f.result()
         else:
-            # frames of different sizes, frame mode, or a model with only the reference's transfer(): per frame, decode
-            # and encode still on the worker threads
+            # frame mode, or a model with only the reference's transfer(): per frame, decode and encode still on the worker threads
             tool = video.ReshapeTool()
             pending = deque()
             look = deque(pool.submit(read_image_bgr, frame_paths[i]) for i in range(lo, min(hi, lo + 2 * nthreads)))
@@ -312,13 +332,24 @@ def stylize_files_multistyle(model, style_paths, frame_paths, out_dir, video_pat
         model.prepare_style([video.resize_bilinear(im, style_size) for im in pool.map(read_image_bgr, style_paths)])
         tool = video.ReshapeTool()
         shapes, feats = [], []
+        batch_encode = getattr(model, "generate_content_features_batch", None)     # absent on a model with the reference's surface only
         look = deque(pool.submit(read_image_bgr, p) for p in frame_paths[:2 * nthreads])
+        group = []                               # padded frames of one size waiting for one batched encoder call
+
+        def flush():
+            if group:
+                feats.extend(batch_encode(group) if batch_encode and len(group) > 1 else [model.generate_content_features(g) for g in group])
+                group.clear()
         for i in range(n):
             f = look.popleft().result()
             if i + 2 * nthreads < n:
                 look.append(pool.submit(read_image_bgr, frame_paths[i + 2 * nthreads]))
             shapes.append(f.shape)
-            feats.append(model.generate_content_features(tool.process(f)))
+            padded = tool.process(f)
+            if group and (padded.shape != group[0].shape or len(group) >= chunk):
+                flush()
+            group.append(padded)
+        flush()
         log("Encoded %d frames; statistics from %d of them" % (n, len(video.sample_indices_multistyle(n))))
         model.clean()
         for i in video.sample_indices_multistyle(n):
@@ -425,12 +456,17 @@ def main(argv=None, model_factory=None):
         rank, world, local = D.init_from_env(os.environ.get("RRV_DRIVER_BACKEND"))
         import torch.distributed as dist
         broadcast, barrier = D.broadcast_state, dist.barrier
+    if args.gpus > 1 and args.device is not None:
+        sys.exit("--device picks the GPU of a single-process run; with --gpus N every rank takes the GPU of its LOCAL_RANK")
     device = args.device if args.device is not None else local
     if model_factory is None:
-        import torch
-        ndev = max(1, torch.cuda.device_count()) if world > 1 else 0
-        if ndev:
-            device = device % ndev
+        if world > 1 and os.environ.get("RRV_DRIVER_BACKEND", "nccl") == "nccl":
+            import torch                      # (a single-process run needs no torch at all)
+            if world > torch.cuda.device_count():
+                sys.exit("--gpus %d but this node has %d GPUs (one rank per GPU over RCCL)" % (world, torch.cuda.device_count()))
+        elif world > 1:                       # gloo control-flow runs: the ranks may share the GPUs there are
+            import torch
+            device = device % max(1, torch.cuda.device_count())
         ckpt = pkg.synthetic_weights(0) if args.checkpoint == "synthetic" else args.checkpoint
         if len(args.style) > 1:     # "Multi-style Interpolation/test.py"
             model = pkg.MultiStyleStylization(ckpt, cuda=True, style_num=len(args.style), device=device)

@@ -285,7 +285,8 @@ class Stylization():
     def transfer_frames(self, frames, out=None):
         """UNPADDED uint8 BGR frames (a list, or one [B][H][W][3] array) -> [B][H][W][3] float32 stylized frames.
         The reference driver's ReshapeTool.process + crop (test/generate_real_video.py:61-83, :167) run on the
-        device: bit-identical to pad -> transfer -> crop, without the padded copies on the host or over PCIe."""
+        device, without the padded copies on the host or over PCIe: the same picture as pad -> transfer -> crop (bit-identical
+        for a fixed kernel choice, set_f43(0) / set_f43(2); the default picks kernels per launch geometry, the crop window included)."""
         if isinstance(frames, np.ndarray) and frames.ndim == 4 and frames.dtype == np.uint8 and frames.shape[3] == 3:
             a = np.ascontiguousarray(frames)
         else:
@@ -311,8 +312,10 @@ class Stylization():
         self._chk(self._lib.rrv_set_caller_stream(self._h, C.c_void_p(stream_ptr), 1 if enable else 0))
 
     def set_f43(self, mode):
-        """Kernel choice for the layers with a Winograd F(4x4,3x3) pack: 0 never, 1 (default) launches of >= 4 frames,
-        2 always (rrv_set_f43)."""
+        """Kernel choice for the ten layers with a Winograd F(4x4,3x3) pack (rrv_set_f43): 0 never; 1 (default) per layer where
+        the launch geometry — frames per launch, frame size, CUs the launch may use — lets it win, so a frame's low-order bits
+        depend on how it was submitted (inside the parity bounds either way); 2 always.  With 0 or 2 every entry delivers
+        the same bits for a frame."""
         self._chk(self._lib.rrv_set_f43(self._h, int(mode)))
 
     def set_grid_share(self, share):
@@ -368,10 +371,10 @@ class Stylization():
         """ncclBroadcast of the style's 17 536-float state from `root`; afterwards this rank holds it as after set_state."""
         self._chk(self._lib.rrv_broadcast_state(self._h, comm, int(root), int(rank), int(style_id)))
 
-    def preclamp(self, H, W):
-        """Pre-clamp network output of the last transfer, NHWC RGB normalised units."""
+    def preclamp(self, H, W, image=0):
+        """Pre-clamp network output of the last transfer (image `image` of its last launch), NHWC RGB normalised units."""
         out = _outputs.empty((H, W, 3))
-        self._chk(self._lib.rrv_get_preclamp(self._h, out.ctypes.data_as(C.c_void_p), H, W))
+        self._chk(self._lib.rrv_get_preclamp_image(self._h, out.ctypes.data_as(C.c_void_p), H, W, int(image)))
         return out
 
     # ===== per-launch timing (HIP events on the library's stream) =====
@@ -409,6 +412,19 @@ class MultiStyleStylization(Stylization):
         fid = C.c_int(-1)
         self._chk(self._lib.rrv_generate_content_features(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], C.byref(fid)))
         return ContentFeature(fid.value, a.shape)
+
+    def generate_content_features_batch(self, frames):
+        """`generate_content_features` for a run of equally sized frames (a list, or one [B][H][W][3] array) in one call:
+        the reference's caching loop ("Multi-style Interpolation/test.py":87-101) pipelined inside the library
+        (rrv_generate_content_features_batch).  Returns one ContentFeature per frame."""
+        if isinstance(frames, np.ndarray) and frames.ndim == 4 and frames.dtype == np.uint8 and frames.shape[3] == 3:
+            a = np.ascontiguousarray(frames)
+        else:
+            a = np.stack([_u8_image(f, "content") for f in frames])
+        B, H, W, _ = a.shape
+        ids = (C.c_int * B)()
+        self._chk(self._lib.rrv_generate_content_features_batch(self._h, a.ctypes.data_as(C.c_void_p), B, H, W, ids))
+        return [ContentFeature(int(i), (H, W, 3)) for i in ids]
 
     def add_patch(self, patch_feature):
         self._chk(self._lib.rrv_add_patch(self._h, patch_feature.id))

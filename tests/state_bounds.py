@@ -103,6 +103,28 @@ def pre_worst(got, ref):
     return float((err / (PRE_ATOL + PRE_RTOL * np.abs(ref))).max()), float(err.max())
 
 
+def pre_full_size(got, ref32, ref64, what="pre-clamp", factor=1.25, pct=99.99, pct_limit=0.5):
+    """Pre-clamp comparison at a BASELINE configuration's FULL size (1.2 - 4 million values of white-noise frames).  There the
+    bound |d| <= PRE_ATOL + PRE_RTOL |ref| on EVERY value is not a property an fp32 evaluation has: the reference's own
+    arithmetic (the oracle with its convolutions on torch's float32 conv2d, `ref32`) misses the same network with every
+    convolution accumulated in float64 (`ref64`) by 2.0 - 2.7x the bound on a handful of pixels behind the near-dead relu4_1
+    channels (Decoder.norm[0]'s rstd up to 4e3 amplifies ~1e-7 of rounding noise), while 99.99 % of its values sit below
+    0.45 of it (profiles/r05_fullsize_margin.txt).  So the HIP path is held to:
+      * against `ref64` (its own error alone): every value inside the bound, or — where the float32 oracle itself leaves the
+        bound — at most `factor` x the float32 oracle's own worst miss;
+      * the `pct`-th percentile of error / bound <= `pct_limit`.
+    Returns (worst, percentile, mean, the float32 oracle's own worst) of error / bound."""
+    r64 = np.asarray(ref64, np.float64)
+    bound = PRE_ATOL + PRE_RTOL * np.abs(r64)
+    mine = np.abs(np.asarray(got, np.float64) - r64) / bound
+    theirs = float((np.abs(np.asarray(ref32, np.float64) - r64) / bound).max())
+    worst, p, mean = float(mine.max()), float(np.percentile(mine, pct)), float(mine.mean())
+    limit = max(1.0, factor * theirs)
+    assert worst <= limit, "%s: worst value at %.2fx the bound from the float64-accumulated oracle (the float32 oracle itself: %.2fx; allowed %.2fx)" % (what, worst, theirs, limit)
+    assert p <= pct_limit, "%s: %.2fth percentile of error / bound is %.3f (limit %.2f)" % (what, pct, p, pct_limit)
+    return worst, p, mean, theirs
+
+
 def _layer_of(field):
     """'dec.norm1.min(x)' -> 'dec.norm1': the four statistics of one normalisation layer come out of one tensor and share
     its conditioning; a filter / a style level is its own group (21 groups)."""

@@ -160,11 +160,26 @@ def test_threaded_chunk_pipeline_equals_serial_flow(tmp_path, pkg, oracle):
         np.testing.assert_array_equal(D.read_image_bgr(p), D.to_uint8(ref[i]))
     b = open(str(tmp_path / "v.avi"), "rb").read()
     assert struct.unpack("<I", b[48:52])[0] == 7                                      # avih.dwTotalFrames
-    # a frame of another size in the list is an error of the fast path, not silent garbage
-    D.write_image_bgr(str(src / "f03.png"), pkg.synth_frame(3, 16, 32, kind="smooth"))
-    with pytest.raises(ValueError):
-        D.stylize_files(_FramesModel(oracle, pkg.synthetic_weights(0)), str(tmp_path / "style.png"), D.list_frames(str(src / "*.png")),
-                        str(tmp_path / "out2"), chunk=4, io_threads=2, log=lambda *_: None)
+    # frames of other sizes in the list: as the reference (generate_real_video.py:152-171 reshapes every frame on its own)
+    # they are stylized, in shorter chunks of equal size — f03 and f04 smaller, then back to the video's size
+    for i in (3, 4):
+        frames[i] = pkg.synth_frame(i, 16, 40, kind="smooth")
+        D.write_image_bgr(str(src / ("f%02d.png" % i)), frames[i])
+    model = _FramesModel(oracle, pkg.synthetic_weights(0))
+    written = D.stylize_files(model, str(tmp_path / "style.png"), D.list_frames(str(src / "*.png")), str(tmp_path / "out2"), chunk=4, io_threads=2,
+                              log=lambda *_: None)
+    assert model.calls == [3, 2, 2]
+    o = oracle.Stylization(pkg.synthetic_weights(0))
+    o.prepare_style(style); o.clean()
+    for i in V.sample_indices(7):
+        o.add(frames[i])
+    o.compute()
+    tool = V.ReshapeTool()
+    for i, p in enumerate(written):
+        H, W = frames[i].shape[:2]
+        tool = V.ReshapeTool()                      # the reference's tool fixes the padded size at its first frame; per size here
+        ref_i = o.transfer(tool.process(frames[i]))[64:64 + H, 64:64 + W]
+        np.testing.assert_array_equal(D.read_image_bgr(p), D.to_uint8(ref_i))
 
 
 def _cli_rank(rank, world, port, argv):

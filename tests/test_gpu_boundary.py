@@ -10,10 +10,20 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import load_golden, golden_inputs, IMG_ATOL
+from conftest import load_golden, golden_inputs, IMG_ATOL, fixed_kernels
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _one_kernel_family():
+    """This module asserts cross-entry invariants bit for bit (page-locked == pageable == tickets == zero copy == debug mode
+    == sharded ...): they hold for a FIXED kernel choice, so every handle created here — in this process and in the child
+    processes, through RRV_F43 — runs F(2x2,3x3).  The same entries with the DEFAULT choice meet the oracle in
+    tests/test_gpu_default_choice.py::test_every_entry_in_the_default_mode_vs_oracle."""
+    with fixed_kernels():
+        yield
 
 
 @pytest.fixture(scope="module")
@@ -401,6 +411,42 @@ def test_feature_cache_cap_falls_back_to_reencoding(pkg, weights, oracle):
     # a re-encoded frame normalises inside the encoder's epilogue instead of a pointwise pass over the cached feature
     assert np.abs(one_cap - one_all).max() <= IMG_ATOL and np.abs(many_cap - many_all).max() <= IMG_ATOL
     np.testing.assert_array_equal(many_cap[:2], many_all[:2])           # the two cached ones are untouched
+
+
+def test_batched_feature_caching_equals_per_frame(pkg, weights, oracle):
+    """rrv_generate_content_features_batch (sub-batches over two streams, the encoder's last layer storing straight into the
+    cache arena) == rrv_generate_content_features frame by frame: the decoder on either feature gives the same bits; page-locked
+    and pageable input, a call that crosses the cache cap (the tail kept as pixels), features of an earlier call still valid,
+    release and re-use."""
+    g = load_golden("multistyle_s2")
+    styles = [pkg.synth_style(64, 64, kind="smooth", seed=7), pkg.synth_style(64, 64, kind="smooth", seed=8)]
+    frames = np.stack([oracle.reflect_pad(pkg.synth_frame(40 + i, 100, 150, kind="noise"), 256, 320) for i in range(21)])
+    s = pkg.MultiStyleStylization(weights, cuda=True, style_num=2)
+    s.set_state(g["state0"], 0)
+    s.set_state(g["state1"], 1)
+    w = [0.3, 0.7]
+    one = [s.generate_content_features(f) for f in frames]
+    ref = np.stack([s.transfer(f, w) for f in one])
+    s.release_features()
+    first = s.generate_content_features_batch(frames[:5])                       # pageable, one sub-batch
+    pin = pkg.pinned_empty(frames.shape, np.uint8)
+    pin[:] = frames
+    rest = s.generate_content_features_batch(pin)                                # page-locked, several sub-batches (ragged last one)
+    assert [f.id for f in first] == list(range(5)) and [f.id for f in rest] == list(range(5, 26))
+    np.testing.assert_array_equal(s.transfer_many(rest, [w] * 21), ref)
+    np.testing.assert_array_equal(s.transfer_many(first, [w] * 5), ref[:5])     # the earlier arena is untouched
+    res, sp, nbytes = s.feature_cache_info()
+    assert (res, sp) == (26, 0)
+    s.release_features()
+    assert s.feature_cache_info() == (0, 0, 0)
+    s.set_feature_cache_cap(nbytes // 26 * 9)                                    # room for about eight features
+    capped = s.generate_content_features_batch(frames)
+    res, sp, _ = s.feature_cache_info()
+    assert 6 <= res <= 9 and res + sp == 21
+    np.testing.assert_array_equal(s.transfer_many(capped[:res], [w] * res), ref[:res])
+    assert np.abs(s.transfer_many(capped[res:], [w] * sp) - ref[res:]).max() <= IMG_ATOL      # spilled: re-encoded on use (the per-frame path's encoder)
+    s.release_features()
+    s.close()
 
 
 def test_c_abi_rccl_broadcast_single_rank(hip, pkg):

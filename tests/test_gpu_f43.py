@@ -1,9 +1,8 @@
 """GPU tests (-m gpu) of the F(4x4,3x3) kernel choice (conv_f43_k; rrv_set_f43, include/rerevst_hip.h): by default the
 library runs the encoder convs conv1_2 .. conv3_4 and the three ResidualBlock.conv2 in F(4x4,3x3) when a launch has
-enough work items.  The rest of the GPU suite pins RRV_F43=0 (tests/conftest.py) — its cross-entry bit-identity
-invariants hold for a FIXED kernel choice — so this module is where the default choice (mode 1) and the kernel on every
-packed layer in every launch (mode 2) meet the reference goldens, the oracle, partial tiles, the crop windows and the
-debug mode."""
+enough work items.  The suite runs in that default (the BASELINE configurations at full size: tests/test_gpu_default_choice.py);
+this module forces the kernel onto every packed layer in every launch (mode 2) so that it meets the reference goldens, the
+oracle, partial tiles, the crop windows and the debug mode also at the small sizes where the default rule would not pick it."""
 import os
 
 import numpy as np

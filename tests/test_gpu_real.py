@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import (load_golden, golden_inputs, decode_png, assert_state_close, assert_pre_close,
-                      assert_state_close_conditioned, IMG_ATOL)
+                      assert_state_close_conditioned, IMG_ATOL, fixed_kernels)
 
 pytestmark = pytest.mark.gpu
 
@@ -35,8 +35,11 @@ def test_real_default_matches_reference(pkg, weights, oracle):
     assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
     assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
     np.testing.assert_allclose(out.mean(axis=(0, 1)), g["out_chanmean"], atol=2e-3)
-    # the on-device pad / crop entry (what driver.py uses) delivers the same pixels
-    np.testing.assert_array_equal(s.transfer_frames([frame])[0], out)
+    # the on-device pad / crop entry (what driver.py uses) delivers the same picture — and, for a fixed kernel choice, the same bits
+    crop = s.transfer_frames([frame])[0]
+    assert np.abs(crop[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
+    with fixed_kernels(s):
+        np.testing.assert_array_equal(s.transfer_frames([frame])[0], s.transfer(oracle.reflect_pad(frame, 576, 1152))[64:500, 64:1088])
     s.close()
 
 
@@ -103,7 +106,8 @@ def test_real_multistyle_matches_reference(pkg, weights, oracle):
     s = pkg.MultiStyleStylization(weights, cuda=True, style_num=2)
     s.prepare_style(styles)
     padded = {i: oracle.reflect_pad(decode_png(g["frame%d_png" % i]), 576, 1152) for i in sorted(set(ids + [tid]))}
-    feats = {i: s.generate_content_features(padded[i]) for i in padded}
+    keys = sorted(padded)
+    feats = dict(zip(keys, s.generate_content_features_batch([padded[i] for i in keys])))      # the batched caching pass, default kernel choice (four 576 x 1152 frames per encoder launch)
     s.clean()
     for i in ids:
         s.add_patch(feats[i])
@@ -121,7 +125,10 @@ def test_real_multistyle_matches_reference(pkg, weights, oracle):
     many = s.transfer_many([feats[tid], feats[0]], [wts, [0.0, 1.0]])                 # the driver's frame loop in one call
     np.testing.assert_array_equal(many[0][64:500, 64:1088], out)
     full = pkg.Stylization.transfer(s, padded[tid], style_weight=wts)[64:500, 64:1088]      # encoder + blended decoder from the frame
-    assert np.abs(full - out).max() <= 1e-3
+    assert np.abs(full[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL                        # (its encoder may run F(4x4,3x3); the cached features never do)
+    with fixed_kernels(s):                 # one kernel family for the encoder of both entries: the same numbers to 1e-3
+        full = pkg.Stylization.transfer(s, padded[tid], style_weight=wts)[64:500, 64:1088]
+        assert np.abs(full - s.transfer(s.generate_content_features(padded[tid]), wts)[64:500, 64:1088]).max() <= 1e-3
     s.release_features()
     s.close()
 

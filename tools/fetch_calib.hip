@@ -7,6 +7,9 @@
 //   stream      : float4 per lane, 1 KB contiguous per wave (the guide's case)
 //   seg64_sNNN  : LDS-DMA, 16 B per lane, 64-byte segments NNN bytes apart (256 = 64-channel tensors, 512, 1024, 2048)
 //   seg256      : LDS-DMA, 256-byte segments (conv_last_k's reads of a 64-channel pixel)
+//   chunkmajor_C: conv_f43_k's pattern — a workgroup owns a block of 1024 pixels of a C-channel tensor and reads it CHUNK-MAJOR:
+//                 for every 8-channel chunk, the 32-byte piece of each pixel (two lanes per pixel); every byte of the
+//                 tensor is read exactly once, each 128-byte line is touched by four consecutive chunk passes
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/fetch_calib.hip -o tools/bin/fetch_calib
 //   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out -o p -- tools/bin/fetch_calib ; python tools/fetch_calib_summary.py <db>
 #include <hip/hip_runtime.h>
@@ -43,6 +46,34 @@ __global__ __launch_bounds__(256) void seg_k(const char* __restrict__ in, float*
     if (((const float*)lds)[threadIdx.x] == 123.456f) out[0] = 1.f;
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void chunkmajor_k(const char* __restrict__ in, float* out, size_t nblocks) {
+    __shared__ __attribute__((aligned(16))) char lds[4096];
+    constexpr int PIX = 1024, ROW = C * 4;           // pixels per block, bytes per pixel
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const char* base = in + blk * (size_t)PIX * ROW;
+        for (int chunk = 0; chunk < C / 8; ++chunk) {
+            // 1024 pixels x 2 lanes = 2048 lanes = 8 instructions per wave
+            for (int it = 0; it < 8; ++it) {
+                const int pixel = (it * 4 + wave) * 32 + (lane >> 1);
+                bufld16(base, lds + wave * 1024, pixel * ROW + (lane & 1) * 16, chunk * 32);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();                         // one chunk pass of the whole block after the other, as the kernel's K loop
+        }
+    }
+    if (((const float*)lds)[threadIdx.x] == 123.456f) out[0] = 1.f;
+}
+
+template <int C>
+void run_chunkmajor(const char* buf, float* out, size_t bytes) {
+    const size_t nblocks = bytes / ((size_t)1024 * C * 4);
+    hipLaunchKernelGGL((chunkmajor_k<C>), dim3(256), dim3(256), 0, 0, buf, out, nblocks);
+    CK(hipDeviceSynchronize());
+    printf("chunkmajor_k<%d>: %zu blocks, %zu useful bytes\n", C, nblocks, nblocks * 1024 * C * 4);
+}
+
 template <int SEG, int STRIDE>
 void run_seg(const char* buf, float* out, size_t bytes) {
     const size_t nseg = bytes / STRIDE;
@@ -67,5 +98,8 @@ int main() {
     run_seg<256, 256>(buf, out, bytes);
     run_seg<32, 256>(buf, out, bytes);
     run_seg<32, 512>(buf, out, bytes);
+    run_chunkmajor<64>(buf, out, bytes);
+    run_chunkmajor<128>(buf, out, bytes);
+    run_chunkmajor<256>(buf, out, bytes);
     return 0;
 }
