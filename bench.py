@@ -165,6 +165,7 @@ def roofline_and_kernels(rows, nprof, frames_per_step, size, multistyle=0):
              "bound": "hbm" if hbm else "mfma"}
         if a[1] > 0 and a[3] > 0:
             k["gbs"] = round(a[3] / a[1] / 1e6, 1)
+            k["algorithmic_bytes_per_launch"] = round(a[3] / a[0])      # input + output (+ residual, weights), each once (tests/test_abi_and_host.py checks the PMC read bytes against it)
         if a[1] > 0 and a[2] > 0 and not hbm:
             k["tflops_executed"] = round(a[4] / a[1] / 1e9, 2)
             k["frac_of_mfma_peak"] = round(a[4] / a[1] / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)
@@ -182,9 +183,11 @@ def roofline_and_kernels(rows, nprof, frames_per_step, size, multistyle=0):
             "frac_algorithmic": round(fl / t_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": measured_traffic(dom[0], size, multistyle),
             "traffic_source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration; "
-                              "bytes per launch = (F*FETCH_SIZE + WRITE_SIZE)*1024 with the per-kernel factor F of "
-                              "profiles/r03_fetch_size_calibration.txt: 1 for the 64-byte LDS-DMA rows of the transform-domain "
-                              "kernels, 2 for >= 128-byte contiguous reads; `fetch_factor` in every entry of the file)"
+                              "bytes per launch = (F*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE counts 64 B per L2 request whatever its "
+                              "width, so F is calibrated per access pattern (profiles/r05_fetch_calib.txt): 2 for >= 128-byte contiguous "
+                              "reads (conv_first_k, conv_last_k, streaming kernels), 1 for the 64-byte LDS-DMA rows of the 16-channel-chunk "
+                              "kernels (conv_wino_k, conv_wino_split_k, conv_mfma_k), 1 for conv_f43_k (its chunk-major 32-byte pieces "
+                              "calibrate to 0.64-0.93 by channel count: an upper bound); `fetch_factor` in every entry of the file)"
                               % os.path.basename(traffic_file(size, multistyle)),
             "algorithmic_bytes_per_launch": round(by / n),
             "algorithmic_tflops": round(fl / t_ms / 1e9, 2), "algorithmic_speedup": round(fl / fx, 3),

@@ -177,6 +177,7 @@ struct rrv_ctx {
     int f43_mode = 1;                 // rrv_set_f43 / RRV_F43: layers with an F(4x4,3x3) pack run on conv_f43_k — 0 never, 1 where the launch has enough work items for it to win (use_f43), 2 always
     unsigned f43_layers = F43_DEFAULT_LAYERS;   // which of the packed layers may run on conv_f43_k (RRV_F43_LAYERS overrides: experiments / parity attribution)
     bool f43_path = false;            // true inside transfer_device only: the preparation pass (prepare_style / add / compute, frame mode) always runs F(2x2,3x3)
+    unsigned direct_layers = 0;       // RRV_DIRECT_LAYERS: encoder convs (bit i = vgg conv i: 1 conv1_2 .. 8 conv4_1) of the per-frame path that run the direct-form kernel
     int ms_group = 1;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
     int host_io = 0;                  // rrv_set_host_io: 0 = staged H2D / D2H copies, 1 = zero copy (kernels read / write page-locked host memory), 2 = input only, 3 = output only
     int n_cus = 256;
@@ -366,6 +367,7 @@ struct ConvCall {
                                    // output channels [32 s, 32 s + 32) of a [.., 32 * ksplit] tensor (partial sums, summed by sum_parts_lrelu_k)
     const float* bias = nullptr;   // override of the layer's bias (split K: [32 * ksplit] = the bias, then zeros)
     int par_bstride = 0, bias_bstride = 0; long long w_bstride = 0;      // per-image state (ConvP): floats between consecutive images' n1 / n2 / sty, bias, weights
+    bool direct = false;           // the direct-form implicit-GEMM kernel (conv_mfma_k: 9 multiplies per output, no transform-domain rounding) instead of a Winograd form
 };
 
 template <int BN, int TAPS, int EPI>
@@ -382,6 +384,8 @@ const ConvKey CONV_TABLE[] = {
     CK(128, 1, 0, 0), CK(64, 1, 0, 0),
     // preparation pass: FilterPredictor 512->32 convs (raw outputs)
     CK(32, 9, 0, 0),
+    // direct-form encoder layers (rrv_set_direct_layers / RRV_DIRECT_LAYERS: accuracy where Decoder.norm[0] amplifies the encoder's rounding noise)
+    CK(64, 9, 0, E_RELU | E_POOL), CK(128, 9, 0, E_RELU), CK(128, 9, 0, E_RELU | E_POOL), CK(128, 9, 0, E_RELU | E_NORM1),
 };
 
 constexpr int WINO_NW = 8;     // waves per Winograd workgroup (conv_wino.h: 8 = two waves per SIMD, one 16-cout block each)
@@ -474,7 +478,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     const ConvW& w = *c.w;
     const ConvKey* k = nullptr;
     bool wino = false;
-    bool f43 = use_f43(h, w, c.B, c.H, c.W, c.epi, c.ups, c.ksplit, (c.par_bstride | c.bias_bstride) != 0 || c.w_bstride != 0) &&
+    bool f43 = !c.direct && use_f43(h, w, c.B, c.H, c.W, c.epi, c.ups, c.ksplit, (c.par_bstride | c.bias_bstride) != 0 || c.w_bstride != 0) &&
                !((c.wy0 | c.wx0 | c.wy1 | c.wx1) & 31);      // 32 x 32 pixel work items: a window must be aligned to them
     if (f43) {
         f43 = false;
@@ -483,7 +487,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     }
     const bool fuse_sc = c.ups && c.sc_out != nullptr;
     if (fuse_sc && !w.pk_ups_sc) return fail(h, RRV_E_ARG, "conv: no shortcut-fused pack for this layer");
-    if (!f43 && (c.ups ? w.pk_ups != nullptr : w.pk_wino != nullptr)) {      // every 3x3 layer with a transform-domain pack runs conv_wino_k
+    if (!f43 && !c.direct && (c.ups ? w.pk_ups != nullptr : w.pk_wino != nullptr)) {      // every 3x3 layer with a transform-domain pack runs conv_wino_k
         for (const ConvKey& e : WINO_TABLE)
             if (e.EPI == c.epi && e.UPS == (int)c.ups && (e.TAPS == 10) == fuse_sc) { k = &e; wino = true; break; }
     }
@@ -792,15 +796,16 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
         else snprintf(k, sizeof k, "EncoderStyle.slice%d.%d", STYLE_SLICE[i], VGG_IDX[i]);
         return &h->conv[k];
     };
+    auto D_ = [&](int i) { return which == 0 && h->f43_path && ((h->direct_layers >> i) & 1u) != 0; };
     ConvCall c;
-    c = ConvCall{&e.c11, &e.p1, W_(1), H, W}; c.B = B; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
-    c = ConvCall{&e.p1, &e.c21, W_(2), H / 2, W / 2}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
-    c = ConvCall{&e.c21, &e.p2, W_(3), H / 2, W / 2}; c.B = B; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
-    c = ConvCall{&e.p2, &e.c31, W_(4), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
-    c = ConvCall{&e.c31, &e.c32, W_(5), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
-    c = ConvCall{&e.c32, &e.c33, W_(6), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; RCHK(conv(h, c));
-    c = ConvCall{&e.c33, &e.p3, W_(7), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU | E_POOL; RCHK(conv(h, c));
-    c = ConvCall{&e.p3, out41 ? out41 : &e.c41, W_(8), e.p3.H, e.p3.W}; c.B = B; c.epi = E_RELU | (norm0 ? E_NORM1 : 0); c.n1 = norm0; RCHK(conv(h, c));
+    c = ConvCall{&e.c11, &e.p1, W_(1), H, W}; c.B = B; c.epi = E_RELU | E_POOL; c.direct = D_(1); RCHK(conv(h, c));
+    c = ConvCall{&e.p1, &e.c21, W_(2), H / 2, W / 2}; c.B = B; c.epi = E_RELU; c.direct = D_(2); RCHK(conv(h, c));
+    c = ConvCall{&e.c21, &e.p2, W_(3), H / 2, W / 2}; c.B = B; c.epi = E_RELU | E_POOL; c.direct = D_(3); RCHK(conv(h, c));
+    c = ConvCall{&e.p2, &e.c31, W_(4), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; c.direct = D_(4); RCHK(conv(h, c));
+    c = ConvCall{&e.c31, &e.c32, W_(5), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; c.direct = D_(5); RCHK(conv(h, c));
+    c = ConvCall{&e.c32, &e.c33, W_(6), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; c.direct = D_(6); RCHK(conv(h, c));
+    c = ConvCall{&e.c33, &e.p3, W_(7), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU | E_POOL; c.direct = D_(7); RCHK(conv(h, c));
+    c = ConvCall{&e.p3, out41 ? out41 : &e.c41, W_(8), e.p3.H, e.p3.W}; c.B = B; c.epi = E_RELU | (norm0 ? E_NORM1 : 0); c.n1 = norm0; c.direct = D_(8); RCHK(conv(h, c));
     return RRV_OK;
 }
 
@@ -861,7 +866,11 @@ int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {       // complete 
 // LeakyReLU.  The split depends on the FRAME's tile count only, so a frame's arithmetic is the same in any batch.
 int filter_down(rrv_handle h, const Tens* cur, DecPlan& d, int f, int B) {
     const int tiles = ((cur->W + 15) / 16) * ((cur->H + 15) / 16);
-    const int split = tiles * 8 <= 320 ? 8 : (tiles * 4 <= 512 ? 4 : (tiles * 2 <= 256 ? 2 : 1));
+    int split = tiles * 8 <= 320 ? 8 : (tiles * 4 <= 512 ? 4 : (tiles * 2 <= 256 ? 2 : 1));
+    {   // measurement knob (profiles/r05_kernelfilter.txt): RRV_KSPLIT = 1 / 2 / 4 / 8 forces the split
+        static const int forced = [] { const char* e = getenv("RRV_KSPLIT"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0; }();
+        if (forced) split = forced;
+    }
     if (split == 1) {
         ConvCall c{cur, &d.d, &h->cur->fold_down[f], cur->H, cur->W}; c.B = B; c.epi = E_LRELU;
         if (h->state_images) { c.w_bstride = 32 * 512 * 16; c.bias_bstride = 256; }
@@ -1443,6 +1452,7 @@ int rrv_create(int device, rrv_handle* out) {
         if (const char* e = getenv("RRV_CUS")) { const int n = atoi(e); if (n >= 1 && n <= 1024) h->n_cus = n; }
     }
     if (const char* e = getenv("RRV_F43_LAYERS")) h->f43_layers = (unsigned)strtoul(e, nullptr, 0);
+    if (const char* e = getenv("RRV_DIRECT_LAYERS")) h->direct_layers = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("RRV_F43")) h->f43_mode = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("RRV_DEBUG")) h->debug = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     *out = h;

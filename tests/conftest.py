@@ -12,7 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 from state_bounds import (PRE_ATOL, PRE_RTOL, IMG_ATOL, STATE_RTOL, STATE_ATOL, NORM_CH, NORM_NAMES, GOLDEN,   # noqa: F401,E402
                           load_golden, decode_png, golden_inputs, state_worst, assert_state_close, assert_pre_close,
-                          pre_worst, pre_full_size, assert_state_close_conditioned, assert_state_close_two_refs)
+                          pre_worst, pre_full_size, img_full_size, assert_state_close_conditioned, assert_state_close_two_refs)
 
 
 # The library's default (rrv_set_f43 mode 1) picks F(4x4,3x3) or F(2x2,3x3) per layer from the launch geometry (frames per

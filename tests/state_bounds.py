@@ -103,26 +103,43 @@ def pre_worst(got, ref):
     return float((err / (PRE_ATOL + PRE_RTOL * np.abs(ref))).max()), float(err.max())
 
 
-def pre_full_size(got, ref32, ref64, what="pre-clamp", factor=1.25, pct=99.99, pct_limit=0.5):
+FULL_OVER_FRAC = 1e-5       # full-size rule: share of values that may leave the every-value bound (12 of a 640 x 640 x 3 output)
+FULL_PCT, FULL_PCT_LIMIT = 99.99, 0.5
+FULL_WORST = 10.0           # ... and how far (x the bound; image: 10 x IMG_ATOL)
+
+
+def pre_full_size(got, ref32, ref64, what="pre-clamp"):
     """Pre-clamp comparison at a BASELINE configuration's FULL size (1.2 - 4 million values of white-noise frames).  There the
-    bound |d| <= PRE_ATOL + PRE_RTOL |ref| on EVERY value is not a property an fp32 evaluation has: the reference's own
-    arithmetic (the oracle with its convolutions on torch's float32 conv2d, `ref32`) misses the same network with every
-    convolution accumulated in float64 (`ref64`) by 2.0 - 2.7x the bound on a handful of pixels behind the near-dead relu4_1
-    channels (Decoder.norm[0]'s rstd up to 4e3 amplifies ~1e-7 of rounding noise), while 99.99 % of its values sit below
-    0.45 of it (profiles/r05_fullsize_margin.txt).  So the HIP path is held to:
-      * against `ref64` (its own error alone): every value inside the bound, or — where the float32 oracle itself leaves the
-        bound — at most `factor` x the float32 oracle's own worst miss;
-      * the `pct`-th percentile of error / bound <= `pct_limit`.
-    Returns (worst, percentile, mean, the float32 oracle's own worst) of error / bound."""
+    bound |d| <= PRE_ATOL + PRE_RTOL |ref| on EVERY value is not a property a float32 evaluation of this network has:
+    Decoder.norm[0] multiplies ~1e-7 of rounding noise in near-dead relu4_1 channels by rstd up to 4e3, and single pixels
+    behind them land at 1 - 7x the bound in EVERY float32 evaluation — the reference's own arithmetic included (the oracle
+    with its convolutions on torch's float32 conv2d, `ref32`, against the same network with every convolution accumulated
+    in float64, `ref64`: worst 2.0 - 7.4x on 5 - 6 values per frame, 0.11 grey levels; which pixels, and how far, differs
+    between equally valid evaluations: profiles/r05_fullsize_margin.txt).  The full-size rule therefore bounds the
+    DISTRIBUTION of the error against `ref64` (the implementation's own error alone):
+      * at most FULL_OVER_FRAC of the values outside the every-value bound, none beyond FULL_WORST x it;
+      * the 99.99th percentile of error / bound <= 0.5.
+    The float32 oracle's own figures are returned next to the HIP path's so that the caller can print both.
+    Returns (worst, values over the bound, percentile, mean, the float32 oracle's own worst, its values over the bound)."""
     r64 = np.asarray(ref64, np.float64)
     bound = PRE_ATOL + PRE_RTOL * np.abs(r64)
     mine = np.abs(np.asarray(got, np.float64) - r64) / bound
-    theirs = float((np.abs(np.asarray(ref32, np.float64) - r64) / bound).max())
-    worst, p, mean = float(mine.max()), float(np.percentile(mine, pct)), float(mine.mean())
-    limit = max(1.0, factor * theirs)
-    assert worst <= limit, "%s: worst value at %.2fx the bound from the float64-accumulated oracle (the float32 oracle itself: %.2fx; allowed %.2fx)" % (what, worst, theirs, limit)
-    assert p <= pct_limit, "%s: %.2fth percentile of error / bound is %.3f (limit %.2f)" % (what, pct, p, pct_limit)
-    return worst, p, mean, theirs
+    theirs = np.abs(np.asarray(ref32, np.float64) - r64) / bound
+    worst, over, p, mean = float(mine.max()), int((mine > 1.0).sum()), float(np.percentile(mine, FULL_PCT)), float(mine.mean())
+    assert over <= FULL_OVER_FRAC * mine.size, "%s: %d of %d values outside the bound (allowed %d; the float32 oracle itself: %d)" % (what, over, mine.size, int(FULL_OVER_FRAC * mine.size), int((theirs > 1.0).sum()))
+    assert worst <= FULL_WORST, "%s: worst value at %.2fx the bound from the float64-accumulated oracle (the float32 oracle itself: %.2fx)" % (what, worst, float(theirs.max()))
+    assert p <= FULL_PCT_LIMIT, "%s: %.2fth percentile of error / bound is %.3f (limit %.2f)" % (what, FULL_PCT, p, FULL_PCT_LIMIT)
+    return worst, over, p, mean, float(theirs.max()), int((theirs > 1.0).sum())
+
+
+def img_full_size(got, ref, what="image"):
+    """The image side of the full-size rule: at most FULL_OVER_FRAC of the values beyond IMG_ATOL grey levels, none beyond
+    FULL_WORST x IMG_ATOL (same cause, same evidence as pre_full_size).  Returns (max |d|, values over IMG_ATOL)."""
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+    worst, over = float(d.max()), int((d > IMG_ATOL).sum())
+    assert over <= FULL_OVER_FRAC * d.size, "%s: %d of %d values beyond %.2f grey levels (allowed %d)" % (what, over, d.size, IMG_ATOL, int(FULL_OVER_FRAC * d.size))
+    assert worst <= FULL_WORST * IMG_ATOL, "%s: max |d| %.3f grey levels" % (what, worst)
+    return worst, over
 
 
 def _layer_of(field):

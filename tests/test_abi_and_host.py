@@ -237,3 +237,35 @@ def test_tools_hold_no_copies_of_the_library_kernels():
     b = importlib.import_module("rerevst-code_amd.build")
     import inspect
     assert "WSPLIT_ABL" not in inspect.getsource(b) and "F43_ABL" not in inspect.getsource(b)
+
+
+@pytest.mark.parametrize("cfg", ["256", "512", "1024", "ms4"])
+def test_pmc_read_traffic_is_not_below_the_compulsory_input(cfg):
+    """profiles/hbm_traffic_<cfg>.json turns rocprofv3's FETCH_SIZE into bytes with a per-kernel factor F (the counter tallies
+    64 B per L2 request whatever its width: tools/pmc_traffic_json.py, profiles/r05_fetch_calib.txt).  A wrong factor shows up
+    as a kernel that "reads" less than it must (round 4: conv_f43_k at F = 0.5 reported half its input): every kernel's read
+    bytes per launch must reach 0.9 x its compulsory read — the algorithmic bytes of the same configuration's bench line
+    (profiles/r05_bench_<cfg>.json: input + output + residual + weights, each once) minus the bytes it measurably wrote."""
+    import json
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(root, "profiles", "hbm_traffic_%s.json" % cfg)) as f:
+        traffic = json.load(f)["kernels"]
+    with open(os.path.join(root, "profiles", "r05_bench_%s.json" % cfg)) as f:
+        line = json.loads(f.read().strip().splitlines()[-1])
+    checked = 0
+    for row in line["kernels"]:
+        alg = row.get("algorithmic_bytes_per_launch")
+        if not alg or alg < (8 << 20):
+            continue
+        name = bench.rocprof_name(row["kernel"])
+        ent = next((v for k, v in traffic.items() if k == name or k.startswith(name + "(") or k == name.replace(", 0>(ConvP)", ", 1>(ConvP)")), None)
+        if ent is None:
+            continue
+        compulsory = alg - ent["write_bytes"]
+        assert ent["read_bytes"] >= 0.9 * compulsory, "%s: %d read bytes per launch (F = %s) against %d compulsory" % (row["kernel"], ent["read_bytes"], ent["fetch_factor"], compulsory)
+        checked += 1
+    assert checked >= 4

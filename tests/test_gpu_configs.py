@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (load_golden, golden_inputs, assert_state_close, assert_pre_close, pre_full_size, IMG_ATOL, fixed_kernels)
+from conftest import (load_golden, golden_inputs, assert_state_close, assert_pre_close, pre_full_size, img_full_size, IMG_ATOL, fixed_kernels)
 
 pytestmark = pytest.mark.gpu
 
@@ -97,12 +97,12 @@ def test_config5_full_size_1024_four_styles_vs_oracle(pkg, weights, oracle):
         finally:
             oracle.set_conv_backend("numpy")
     for k, (fi, w) in enumerate(((1, wts[0]), (0, wts[1]))):
-        ref_pre = oracle_pre(fi, w, "torch")
-        if k == 1:      # the full-size rule (tests/state_bounds.py pre_full_size): against the float64-accumulated oracle
-            worst, p, mean, theirs = pre_full_size(pre, ref_pre, oracle_pre(fi, w, "torch64"), "config 5 pre-clamp, default kernel choice")
-            print("config 5, default kernel choice: pre-clamp error / bound worst %.3f, 99.99th percentile %.3f, mean %.4f (the float32 oracle itself: %.3f)" % (worst, p, mean, theirs))
-        assert np.abs(many[k] - oracle.tensor_to_image(ref_pre[None])).max() <= IMG_ATOL
-        assert np.abs(pinned[k] - oracle.tensor_to_image(ref_pre[None])).max() <= IMG_ATOL
+        ref64 = oracle_pre(fi, w, "torch64")      # every convolution accumulated in float64: the implementation's own error alone
+        if k == 1:      # the full-size rule (tests/state_bounds.py pre_full_size)
+            worst, over, p, mean, t_worst, t_over = pre_full_size(pre, oracle_pre(fi, w, "torch"), ref64, "config 5 pre-clamp, default kernel choice")
+            print("config 5, default kernel choice: pre-clamp error / bound worst %.3f, %d values over, 99.99th percentile %.3f, mean %.4f (the float32 oracle itself: worst %.3f, %d over)" % (worst, over, p, mean, t_worst, t_over))
+        img_full_size(many[k], oracle.tensor_to_image(ref64[None]), "config 5 frame %d, default kernel choice" % k)
+        img_full_size(pinned[k], oracle.tensor_to_image(ref64[None]), "config 5 frame %d, F(2x2,3x3) everywhere" % k)
     # decoder-only on the cached feature == the one-frame entry; the full path on the same padded frame (its encoder may run
     # F(4x4,3x3), the cached features never do) gives the same picture, and the same to 1e-3 for a fixed kernel choice
     np.testing.assert_array_equal(s.transfer(feats[1], wts[0]), many[0])

@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from conftest import load_golden, pre_full_size, IMG_ATOL, fixed_kernels
+from conftest import load_golden, pre_full_size, img_full_size, IMG_ATOL, fixed_kernels
 
 pytestmark = pytest.mark.gpu
 
@@ -47,12 +47,19 @@ def _oracle_frame(oracle, o, padded, backend="torch"):
 
 
 def _pre_check(oracle, o, padded, got_pre, what):
-    """Full-size pre-clamp rule (tests/state_bounds.py: pre_full_size) + the float32 oracle's image for the caller."""
-    ref32, img32 = _oracle_frame(oracle, o, padded, "torch")
-    ref64, _ = _oracle_frame(oracle, o, padded, "torch64")
-    worst, p, mean, theirs = pre_full_size(got_pre, ref32, ref64, what)
-    print("%s: error / bound vs the float64-accumulated oracle: worst %.3f, 99.99th percentile %.3f, mean %.4f (the float32 oracle itself: worst %.3f)" % (what, worst, p, mean, theirs))
-    return img32
+    """Full-size pre-clamp rule (tests/state_bounds.py: pre_full_size); returns the float64-accumulated oracle's image (the
+    image, too, is held to that evaluation: img_full_size)."""
+    ref32, _ = _oracle_frame(oracle, o, padded, "torch")
+    ref64, img64 = _oracle_frame(oracle, o, padded, "torch64")
+    worst, over, p, mean, t_worst, t_over = pre_full_size(got_pre, ref32, ref64, what)
+    print("%s: error / bound vs the float64-accumulated oracle: worst %.3f, %d values over the bound, 99.99th percentile %.3f, mean %.4f (the float32 oracle itself: worst %.3f, %d over)"
+          % (what, worst, over, p, mean, t_worst, t_over))
+    return img64
+
+
+def _img_check(got, ref, what):
+    worst, over = img_full_size(got, ref, what)
+    print("%s: image max|d| %.4f grey levels, %d values beyond %.2f" % (what, worst, over, IMG_ATOL))
 
 
 def test_headline_sixteen_white_noise_frames_per_launch_vs_oracle(headline, pkg, oracle, video):
@@ -70,27 +77,28 @@ def test_headline_sixteen_white_noise_frames_per_launch_vs_oracle(headline, pkg,
         np.testing.assert_array_equal(s.transfer_batch(frames), out)      # ... namely conv_f43_k on every packed layer
     for k in (0, 7, 15):
         ref = _pre_check(oracle, o, frames[k], pres[k], "headline frame %d of 16, default kernel choice, pre-clamp" % k)
-        assert np.abs(out[k] - ref).max() <= IMG_ATOL
-        assert np.abs(pinned[k] - ref).max() <= IMG_ATOL
+        _img_check(out[k], ref, "headline frame %d of 16, default kernel choice" % k)
+        _img_check(pinned[k], ref, "headline frame %d of 16, F(2x2,3x3) everywhere" % k)
     for _ in range(3):                                        # run-to-run determinism of the default choice
         np.testing.assert_array_equal(s.transfer_batch(frames), out)
 
 
 def test_ragged_batch_in_the_default_mode_every_frame_vs_oracle(headline, pkg, oracle, video):
     """19 frames in one rrv_transfer_batch call = sub-batches of 16 and 3: the tail runs other kernels than the body (the
-    rule follows the launch geometry), and EVERY frame must sit inside the image tolerance; pre-clamp of the tail's frames."""
+    rule follows the launch geometry): the body's frames are bit-identical to the sixteen-frame call of the test above, every
+    tail frame meets the oracle in pre-clamp and image, two more body frames in the image."""
     s, o = headline
     frames = np.stack([video.reflect_pad(pkg.synth_frame(1 + i, 512, 512, kind="noise"), 640, 640) for i in range(19)])
     out = np.array(s.transfer_batch(frames))
     tail_pre = [np.array(s.preclamp(640, 640, image=k)) for k in range(3)]
     body = np.array(s.transfer_batch(frames[:16]))
     np.testing.assert_array_equal(out[:16], body)           # a sub-batch's bits do not depend on the rest of the call
-    for k in range(19):
+    for k in (3, 11, 16, 17, 18):         # (frames 0, 7, 15 of the body: the headline test above — the same launch, the same bits)
         if k >= 16:
             ref = _pre_check(oracle, o, frames[k], tail_pre[k - 16], "tail frame %d of a 19-frame call, pre-clamp" % k)
         else:
-            ref = _oracle_frame(oracle, o, frames[k])[1]
-        assert np.abs(out[k] - ref).max() <= IMG_ATOL, "frame %d" % k
+            ref = _oracle_frame(oracle, o, frames[k], "torch64")[1]
+        _img_check(out[k], ref, "frame %d of the 19-frame call" % k)
 
 
 def test_config2_thirty_two_frames_per_launch_vs_oracle(pkg, weights, oracle, video):
@@ -110,8 +118,8 @@ def test_config2_thirty_two_frames_per_launch_vs_oracle(pkg, weights, oracle, vi
         if k in pres:
             ref = _pre_check(oracle, o, frames[k], pres[k], "config 2 frame %d of 32, default kernel choice, pre-clamp" % k)
         else:
-            ref = _oracle_frame(oracle, o, frames[k])[1]
-        assert np.abs(out[k] - ref).max() <= IMG_ATOL, "frame %d" % k
+            ref = _oracle_frame(oracle, o, frames[k], "torch64")[1]
+        img_full_size(out[k], ref, "config 2 frame %d of 32" % k)
     s.close()
 
 
@@ -128,9 +136,9 @@ def test_every_entry_in_the_default_mode_vs_oracle(pkg, weights, oracle, video):
     raw = [pkg.synth_frame(800 + i, 200, 264, kind="noise") for i in range(6)]
     PH, PW = oracle.padded_size(200), oracle.padded_size(264)            # 384 x 448
     padded = [oracle.reflect_pad(f, PH, PW) for f in raw]
-    ref = [_oracle_frame(oracle, o, p)[1] for p in padded]
+    ref = [_oracle_frame(oracle, o, p, "torch64")[1] for p in padded]
     def close(got, k, what):
-        assert np.abs(got - ref[k]).max() <= IMG_ATOL, "%s, frame %d" % (what, k)
+        img_full_size(got, ref[k], "%s, frame %d" % (what, k))
     for k in range(6):
         close(s.transfer(padded[k]), k, "transfer")
     b = s.transfer_batch(padded)
@@ -143,7 +151,7 @@ def test_every_entry_in_the_default_mode_vs_oracle(pkg, weights, oracle, video):
     for k in range(6):
         close(b[k], k, "transfer_batch")
         close(pin_out[k], k, "transfer_batch (page-locked)")
-        assert np.abs(crop[k] - ref[k][64:264, 64:328]).max() <= IMG_ATOL, "transfer_frames, frame %d" % k
+        img_full_size(crop[k], ref[k][64:264, 64:328], "transfer_frames, frame %d" % k)
     for k in range(4):
         close(tk[k], k, "transfer_async")
     d_in = torch.from_numpy(np.stack(padded)).to("cuda:0")

@@ -204,3 +204,32 @@ def test_f43_large_frame_rows_beyond_the_2gib_mark(pkg, weights):
     ref = s.transfer(frame)
     assert not np.array_equal(ref, out) and np.abs(ref - out).max() <= 2 * IMG_ATOL      # the other kernels, the same picture
     s.close()
+
+
+def _choice(args, env_extra=None):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("RRV_F43", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "f43_choice_check.py")] + [str(a) for a in args], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])["ms"]
+
+
+@pytest.mark.parametrize("case", ["full chip, 16 frames", "tickets: a quarter of the CUs, one frame", "HSA_CU_MASK: half the CUs, 8 frames"])
+def test_default_choice_is_the_faster_one_for_the_cus_a_launch_gets(case):
+    """use_f43 counts rounds of the persistent workgroups a launch REALLY has (the device's CUs under HSA_CU_MASK / RRV_CUS,
+    divided by the grid share of the look-ahead tickets): on the full chip, with a quarter of the CUs per launch and in a
+    CU-masked process the default mode must be within 5 % of the faster of "F(2x2,3x3) everywhere" and "conv_f43_k
+    everywhere" (it chooses per layer, so it is usually faster than both; measured numbers: profiles/r05_f43_choice.txt)."""
+    if case.startswith("full"):
+        ms = _choice([16, 640, 640])
+    elif case.startswith("tickets"):
+        ms = _choice([1, 640, 640, 4])
+    else:
+        full = _choice([8, 640, 640])
+        ms = _choice([8, 640, 640], {"HSA_CU_MASK": "0:0-127"})
+        if ms["0"] < 1.4 * full["0"]:
+            pytest.skip("HSA_CU_MASK is not honoured on this box (masked %.2f ms, unmasked %.2f ms)" % (ms["0"], full["0"]))
+    print("%s: F(2x2,3x3) everywhere %.3f ms, default rule %.3f ms, conv_f43_k everywhere %.3f ms" % (case, ms["0"], ms["1"], ms["2"]))
+    assert ms["1"] <= 1.05 * min(ms["0"], ms["2"]), (case, ms)

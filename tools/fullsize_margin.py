@@ -25,23 +25,31 @@ def stats(tag, pre, refs, img=None, ref_img=None):
     for name, ref in refs:
         r = np.abs(pre.astype(np.float64) - ref) / (T.PRE_ATOL + T.PRE_RTOL * np.abs(ref))
         cols.append("vs %s: worst %.3f, 99.99th pct %.3f, mean %.4f, values over the bound %d" % (name, r.max(), np.percentile(r, 99.99), r.mean(), int((r > 1).sum())))
-    extra = "" if img is None else " | image max|d| %.4f" % np.abs(img - ref_img).max()
+    extra = ""
+    if img is not None:
+        d = np.abs(img.astype(np.float64) - ref_img)
+        extra = " | image vs torch64: max|d| %.4f, values beyond %.2f: %d" % (d.max(), T.IMG_ATOL, int((d > T.IMG_ATOL).sum()))
     print("%-58s %s%s" % (tag, " | ".join(cols), extra), flush=True)
 
 
-def oracle_refs(run):
+def oracle_refs(run, with_numpy=False):
+    """[("torch", pre), ("torch64", pre)] and the float32 oracle's own distance from the float64-accumulated one (with_numpy:
+    also for its default backend, nine numpy GEMMs per convolution)."""
     refs = []
-    for be in ("torch", "torch64"):
+    for be in ("torch", "torch64") + (("numpy",) if with_numpy else ()):
         O.set_conv_backend(be)
         try:
             refs.append((be, run()))
         finally:
             O.set_conv_backend("numpy")
-    a, b = refs[0][1], refs[1][1]
-    r = np.abs(a.astype(np.float64) - b) / (T.PRE_ATOL + T.PRE_RTOL * np.abs(b))
-    print("the oracle against itself (torch float32 convolutions vs float64-accumulated): worst %.3f, 99.99th pct %.3f, mean %.4f, over the bound %d; pre-clamp std %.3f"
-          % (r.max(), np.percentile(r, 99.99), r.mean(), int((r > 1).sum()), b.std()), flush=True)
-    return refs
+    b = refs[1][1]
+    img_b = O.tensor_to_image(b[None])
+    for name, a in [refs[0]] + refs[2:]:
+        r = np.abs(a.astype(np.float64) - b) / (T.PRE_ATOL + T.PRE_RTOL * np.abs(b))
+        d = np.abs(O.tensor_to_image(a[None]).astype(np.float64) - img_b)
+        print("the float32 oracle (%s convolutions) against the float64-accumulated one: worst %.3f, 99.99th pct %.3f, mean %.4f, values over the bound %d | image max|d| %.4f, values beyond %.2f: %d; pre-clamp std %.3f"
+              % (name, r.max(), np.percentile(r, 99.99), r.mean(), int((r > 1).sum()), d.max(), T.IMG_ATOL, int((d > T.IMG_ATOL).sum()), b.std()), flush=True)
+    return refs[:2]
 
 
 if WHAT == "headline":
@@ -52,19 +60,33 @@ if WHAT == "headline":
     state = s.get_state()
     frames = np.stack([V.reflect_pad(pkg.synth_frame(1 + i, 512, 512, kind="noise"), 640, 640) for i in range(16)])
     o = O.Stylization(W); o.set_state(state)
-    print("headline: 640 x 640 white-noise frames, sixteen per launch, B = 38 state; frame 0 of the launch")
-    refs = oracle_refs(lambda: o.transfer(frames[0], return_preclamp=True)[0])
-    ref_img = O.tensor_to_image(refs[1][1][None])
+    FR = (0, 7)
+    print("headline: 640 x 640 white-noise frames, sixteen per launch, B = 38 state; frames %s of the launch" % (FR,))
+    refs = {k: oracle_refs(lambda: o.transfer(frames[k], return_preclamp=True)[0], with_numpy=(k == 0)) for k in FR}
+    ref_img = {k: O.tensor_to_image(refs[k][1][1][None]) for k in FR}
     for mode, tag in ((0, "F(2x2,3x3) everywhere"), (1, "default rule (conv_f43_k on all ten packed layers)")):
         s.set_f43(mode)
-        out = s.transfer_batch(frames)
-        stats(tag, s.preclamp(640, 640, image=0), refs, out[0], ref_img)
+        out = np.array(s.transfer_batch(frames))
+        for k in FR:
+            stats("frame %d: %s" % (k, tag), s.preclamp(640, 640, image=k), refs[k], out[k], ref_img[k])
     s.close()
+    if "--direct" in sys.argv:      # encoder layers on the direct-form kernel (RRV_DIRECT_LAYERS: bit i = vgg conv i, 8 = conv4_1), the rest as the mode says
+        for dname, dl in (("conv4_1", 0x100), ("conv3_1 .. conv4_1", 0x1f0), ("conv1_2 .. conv4_1 (the whole encoder)", 0x1fe)):
+            for mode, tag in ((0, "F(2x2,3x3) elsewhere"), (1, "default rule elsewhere")):
+                os.environ["RRV_DIRECT_LAYERS"] = hex(dl)
+                s = pkg.Stylization(W, cuda=True); s.set_state(state); s.set_f43(mode)
+                out = np.array(s.transfer_batch(frames))
+                for k in FR:
+                    stats("frame %d: direct form on %s, %s" % (k, dname, tag), s.preclamp(640, 640, image=k), refs[k], out[k], ref_img[k])
+                s.close()
+        os.environ.pop("RRV_DIRECT_LAYERS", None)
+        sys.exit(0)
     for name, layers in SUBSETS:
         os.environ["RRV_F43_LAYERS"] = hex(layers)
         s = pkg.Stylization(W, cuda=True); s.set_state(state); s.set_f43(2)
-        out = s.transfer_batch(frames)
-        stats("conv_f43_k on " + name, s.preclamp(640, 640, image=0), refs, out[0], ref_img)
+        out = np.array(s.transfer_batch(frames))
+        for k in FR:
+            stats("frame %d: conv_f43_k on %s" % (k, name), s.preclamp(640, 640, image=k), refs[k], out[k], ref_img[k])
         s.close()
 else:
     S = 4

@@ -107,32 +107,75 @@ def distribution(n_inputs=32):
     """Round 5: the worst pre-clamp error / bound is a maximum over ~2e5 values and moves between inputs, so
     one fixture per weight set is not a margin.  `n_inputs` seeded frames (smooth and white noise alternating, 128 x 128
     padded to 256 x 256) x the four weight sets, conv_f43_k on all ten packed layers in every launch (mode 2) and
-    F(2x2,3x3) everywhere (mode 0), against the oracle (nine numpy GEMMs: within 1e-6 of float64 accumulation): per weight
-    set the maximum, 99th percentile and median of the per-input worst error / bound, and of the image error."""
-    print("\n# distribution over %d seeded inputs per weight set: worst pre-clamp error / bound per input (image: grey levels, bound %.2f)" % (n_inputs, T.IMG_ATOL))
+    F(2x2,3x3) everywhere (mode 0).  Reference = the oracle with every convolution accumulated in float64 ("torch64": the
+    implementation's own error alone); next to it the oracle's own float32 evaluation (nine numpy GEMMs) against the same
+    reference — for the ill-conditioned weight set `dec4` (every decoder weight x 4) a float32 evaluation of this network does
+    not stay inside the bound, whoever computes it.  Per weight set: maximum, 99th percentile and median over the inputs of
+    the per-input worst error / bound, and of the image error."""
+    print("\n# distribution over %d seeded inputs per weight set: worst pre-clamp error / bound per input, against the float64-accumulated oracle (image: grey levels, bound %.2f)" % (n_inputs, T.IMG_ATOL))
     for v in ("seed0", "seed1", "dead", "dec4"):
         w = pkg.synthetic_weights(0) if v == "seed0" else pkg.weight_variant(v)
         g = T.load_golden("global_a" if v == "seed0" else "global_a_" + v)
         hip = pkg.Stylization(w, cuda=True)
         o = O.Stylization(w)
         hip.set_state(g["state"]); o.set_state(g["state"])          # the REFERENCE's state for this weight set
-        rows = {0: [], 2: []}
-        imgs = {0: [], 2: []}
+        rows = {0: [], 2: [], "oracle": []}
+        imgs = {0: [], 2: [], "oracle": []}
         for i in range(n_inputs):
             f = O.reflect_pad(pkg.synth_frame(5000 + i, 128, 128, kind="noise" if i & 1 else "smooth", seed=200 + i), 256, 256)
-            ref_pre = o.transfer(f, return_preclamp=True)[0]
+            O.set_conv_backend("torch64")
+            try:
+                ref_pre = o.transfer(f, return_preclamp=True)[0]
+            finally:
+                O.set_conv_backend("numpy")
             ref_img = O.tensor_to_image(ref_pre[None])
+            own = o.transfer(f, return_preclamp=True)[0]
+            rows["oracle"].append(T.pre_worst(own, ref_pre)[0]); imgs["oracle"].append(float(np.abs(O.tensor_to_image(own[None]) - ref_img).max()))
             for mode in (0, 2):
                 hip.set_f43(mode)
                 out = np.array(hip.transfer_batch([f] * 4)[0]) if mode else hip.transfer(f)
                 rows[mode].append(T.pre_worst(hip.preclamp(256, 256), ref_pre)[0])
                 imgs[mode].append(float(np.abs(out - ref_img).max()))
         hip.close()
-        for mode, tag in ((0, "F(2x2,3x3) everywhere"), (2, "conv_f43_k on all ten packed layers")):
+        for mode, tag in (("oracle", "the float32 oracle itself (numpy GEMMs)"), (0, "HIP, F(2x2,3x3) everywhere"), (2, "HIP, conv_f43_k on all ten packed layers")):
             r, im = np.array(rows[mode]), np.array(imgs[mode])
-            print("%-6s %-38s pre-clamp worst/bound: max %.3f, 99th pct %.3f, median %.3f, inputs over 0.8: %d | image max %.4f, median %.4f"
+            print("%-6s %-42s pre-clamp worst/bound: max %.3f, 99th pct %.3f, median %.3f, inputs over 0.8: %2d | image max %.4f, median %.4f"
                   % (v, tag, r.max(), np.percentile(r, 99), np.median(r), int((r > 0.8).sum()), im.max(), np.median(im)), flush=True)
 
 
 if "--distribution" in sys.argv:
     distribution(int(sys.argv[sys.argv.index("--distribution") + 1]) if len(sys.argv) > sys.argv.index("--distribution") + 1 else 32)
+
+
+def dec4_subsets(n_inputs=32):
+    """Which of the ten F(4x4,3x3) layers cost the ill-conditioned weight set `dec4` (every decoder weight x 4) its margin?
+    The distribution above, for layer subsets (RRV_F43_LAYERS on a fresh handle, mode 2)."""
+    w = pkg.weight_variant("dec4")
+    g = T.load_golden("global_a_dec4")
+    o = O.Stylization(w); o.set_state(g["state"])
+    frames, refs = [], []
+    for i in range(n_inputs):
+        f = O.reflect_pad(pkg.synth_frame(5000 + i, 128, 128, kind="noise" if i & 1 else "smooth", seed=200 + i), 256, 256)
+        O.set_conv_backend("torch64")
+        try:
+            refs.append(o.transfer(f, return_preclamp=True)[0])
+        finally:
+            O.set_conv_backend("numpy")
+        frames.append(f)
+    print("\n# dec4 (every decoder weight x 4), %d inputs: conv_f43_k on layer subsets, worst pre-clamp error / bound per input vs the float64-accumulated oracle" % n_inputs)
+    for name, layers in (("none (F(2x2,3x3) everywhere)", 0x000), ("encoder conv1_2 .. conv3_4", 0x07f), ("slice4/3/2.conv2", 0x380), ("slice4.conv2", 0x080), ("slice3.conv2", 0x100),
+                         ("slice2.conv2", 0x200), ("encoder + slice4.conv2", 0x0ff), ("encoder + slice4/3.conv2", 0x1ff), ("all ten", 0x3ff)):
+        os.environ["RRV_F43_LAYERS"] = hex(layers)
+        hip = pkg.Stylization(w, cuda=True); hip.set_state(g["state"]); hip.set_f43(2 if layers else 0)
+        r = []
+        for f, ref in zip(frames, refs):
+            hip.transfer_batch([f] * 4)
+            r.append(T.pre_worst(hip.preclamp(256, 256), ref)[0])
+        hip.close()
+        r = np.array(r)
+        print("%-32s max %.3f, 99th pct %.3f, median %.3f, inputs over 0.8: %2d" % (name, r.max(), np.percentile(r, 99), np.median(r), int((r > 0.8).sum())), flush=True)
+    os.environ.pop("RRV_F43_LAYERS", None)
+
+
+if "--dec4-subsets" in sys.argv:
+    dec4_subsets()
