@@ -103,42 +103,56 @@ def pre_worst(got, ref):
     return float((err / (PRE_ATOL + PRE_RTOL * np.abs(ref))).max()), float(err.max())
 
 
-FULL_OVER_FRAC = 1e-5       # full-size rule: share of values that may leave the every-value bound (12 of a 640 x 640 x 3 output)
+# ---- full-size rule (round 5) ----------------------------------------------------------------------------------------
+# At a BASELINE configuration's full size (1.2 - 4 million values per white-noise frame) the every-value bounds above are
+# not a property a float32 evaluation of this network has.  Decoder.norm[0] multiplies ~1e-7 of rounding noise in near-dead
+# relu4_1 channels by rstd up to 4e3; where such a channel carries signal, a patch of pixels behind it lands at several
+# times the bound in EVERY float32 evaluation — against the same network with every convolution accumulated in float64
+# ("torch64") the reference's own arithmetic (the oracle on torch's float32 conv2d) sits at 2.0 - 7.4x the pre-clamp bound
+# on 5 - 51 values per frame and up to 0.08 grey levels, the library's DIRECT-form fp32-MFMA convolution on the whole
+# encoder at 9.8x / 75 values / 0.11 grey levels, F(2x2,3x3) at 2.0 - 15x, F(4x4,3x3) at 1.0 - 2.7x (which evaluation is
+# hit how hard differs from frame to frame: profiles/r05_fullsize_margin.txt).  So at full size the HIP path is held,
+# against the float64-accumulated oracle (= its own error alone), to
+#   * a strict bound on what is typical: mean error / bound <= FULL_MEAN, the 99.99th percentile <= FULL_PCT_LIMIT;
+#   * a bound on the tail RELATIVE to the reference arithmetic's own tail on the same frame: values outside the every-value
+#     bound <= max(FULL_OVER_FRAC of all, 4 x the float32 oracle's count), worst value <= max(FULL_WORST, 3 x its worst)
+#     (image: 10 x its count, 3 x its worst) — no looser than what the reference's own float32 evaluation does there.
+FULL_OVER_FRAC = 1e-5       # 12 of a 640 x 640 x 3 output
 FULL_PCT, FULL_PCT_LIMIT = 99.99, 0.5
-FULL_WORST = 10.0           # ... and how far (x the bound; image: 10 x IMG_ATOL)
+FULL_MEAN = 0.03
+FULL_WORST = 4.0            # x the pre-clamp bound; image: x IMG_ATOL
 
 
 def pre_full_size(got, ref32, ref64, what="pre-clamp"):
-    """Pre-clamp comparison at a BASELINE configuration's FULL size (1.2 - 4 million values of white-noise frames).  There the
-    bound |d| <= PRE_ATOL + PRE_RTOL |ref| on EVERY value is not a property a float32 evaluation of this network has:
-    Decoder.norm[0] multiplies ~1e-7 of rounding noise in near-dead relu4_1 channels by rstd up to 4e3, and single pixels
-    behind them land at 1 - 7x the bound in EVERY float32 evaluation — the reference's own arithmetic included (the oracle
-    with its convolutions on torch's float32 conv2d, `ref32`, against the same network with every convolution accumulated
-    in float64, `ref64`: worst 2.0 - 7.4x on 5 - 6 values per frame, 0.11 grey levels; which pixels, and how far, differs
-    between equally valid evaluations: profiles/r05_fullsize_margin.txt).  The full-size rule therefore bounds the
-    DISTRIBUTION of the error against `ref64` (the implementation's own error alone):
-      * at most FULL_OVER_FRAC of the values outside the every-value bound, none beyond FULL_WORST x it;
-      * the 99.99th percentile of error / bound <= 0.5.
-    The float32 oracle's own figures are returned next to the HIP path's so that the caller can print both.
-    Returns (worst, values over the bound, percentile, mean, the float32 oracle's own worst, its values over the bound)."""
+    """Pre-clamp side of the full-size rule above.  `ref32`: the oracle with its convolutions on torch's float32 conv2d;
+    `ref64`: with every convolution accumulated in float64.  Returns (worst, values over the bound, 99.99th percentile, mean,
+    the float32 oracle's own worst, its values over the bound) of error / bound."""
     r64 = np.asarray(ref64, np.float64)
     bound = PRE_ATOL + PRE_RTOL * np.abs(r64)
     mine = np.abs(np.asarray(got, np.float64) - r64) / bound
     theirs = np.abs(np.asarray(ref32, np.float64) - r64) / bound
     worst, over, p, mean = float(mine.max()), int((mine > 1.0).sum()), float(np.percentile(mine, FULL_PCT)), float(mine.mean())
-    assert over <= FULL_OVER_FRAC * mine.size, "%s: %d of %d values outside the bound (allowed %d; the float32 oracle itself: %d)" % (what, over, mine.size, int(FULL_OVER_FRAC * mine.size), int((theirs > 1.0).sum()))
-    assert worst <= FULL_WORST, "%s: worst value at %.2fx the bound from the float64-accumulated oracle (the float32 oracle itself: %.2fx)" % (what, worst, float(theirs.max()))
-    assert p <= FULL_PCT_LIMIT, "%s: %.2fth percentile of error / bound is %.3f (limit %.2f)" % (what, FULL_PCT, p, FULL_PCT_LIMIT)
-    return worst, over, p, mean, float(theirs.max()), int((theirs > 1.0).sum())
+    t_worst, t_over, t_p = float(theirs.max()), int((theirs > 1.0).sum()), float(np.percentile(theirs, FULL_PCT))
+    assert mean <= FULL_MEAN, "%s: mean error / bound %.4f (limit %.2f)" % (what, mean, FULL_MEAN)
+    assert p <= max(FULL_PCT_LIMIT, 2.0 * t_p), "%s: %.2fth percentile of error / bound is %.3f (limit %.2f; the float32 oracle itself: %.3f)" % (what, FULL_PCT, p, FULL_PCT_LIMIT, t_p)
+    allowed = max(int(FULL_OVER_FRAC * mine.size), 4 * t_over)
+    assert over <= allowed, "%s: %d of %d values outside the bound (allowed %d; the float32 oracle itself: %d)" % (what, over, mine.size, allowed, t_over)
+    assert worst <= max(FULL_WORST, 3.0 * t_worst), "%s: worst value at %.2fx the bound from the float64-accumulated oracle (the float32 oracle itself: %.2fx)" % (what, worst, t_worst)
+    return worst, over, p, mean, t_worst, t_over
 
 
-def img_full_size(got, ref, what="image"):
-    """The image side of the full-size rule: at most FULL_OVER_FRAC of the values beyond IMG_ATOL grey levels, none beyond
-    FULL_WORST x IMG_ATOL (same cause, same evidence as pre_full_size).  Returns (max |d|, values over IMG_ATOL)."""
+def img_full_size(got, ref, what="image", ref32=None):
+    """Image side of the full-size rule: `ref` = the float64-accumulated oracle's image, `ref32` (optional) the float32
+    oracle's.  Returns (max |d|, values beyond IMG_ATOL)."""
     d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
     worst, over = float(d.max()), int((d > IMG_ATOL).sum())
-    assert over <= FULL_OVER_FRAC * d.size, "%s: %d of %d values beyond %.2f grey levels (allowed %d)" % (what, over, d.size, IMG_ATOL, int(FULL_OVER_FRAC * d.size))
-    assert worst <= FULL_WORST * IMG_ATOL, "%s: max |d| %.3f grey levels" % (what, worst)
+    t_worst, t_over = 0.0, 0
+    if ref32 is not None:
+        t = np.abs(np.asarray(ref32, np.float64) - np.asarray(ref, np.float64))
+        t_worst, t_over = float(t.max()), int((t > IMG_ATOL).sum())
+    allowed = max(int(FULL_OVER_FRAC * d.size), 10 * t_over)
+    assert over <= allowed, "%s: %d of %d values beyond %.2f grey levels (allowed %d; the float32 oracle itself: %d)" % (what, over, d.size, IMG_ATOL, allowed, t_over)
+    assert worst <= max(FULL_WORST * IMG_ATOL, 3.0 * t_worst), "%s: max |d| %.3f grey levels (the float32 oracle itself: %.3f)" % (what, worst, t_worst)
     return worst, over
 
 
@@ -150,19 +164,19 @@ def _layer_of(field):
 
 def _field_limits(ref_a, ref_b, factor):
     """Limit per field from the two references' own disagreement: a LAYER in which they disagree by more than the regular
-    bound is ill-conditioned — its fields get `factor` x the references' WORST disagreement (where in the chain the
-    amplified rounding noise surfaces differs between equally valid float32 evaluations: profiles/r04_dec4_conditioning.txt);
-    every other layer keeps max(1, factor x its own disagreement), i.e. essentially the regular bound.
+    bound is ill-conditioned — its fields get `factor` x THAT layer's own worst disagreement (the four statistics of a
+    normalisation layer share one tensor and its conditioning); every other layer keeps max(1, factor x its own
+    disagreement), i.e. essentially the regular bound.  (Until round 4 an ill-conditioned layer borrowed the GLOBAL worst
+    disagreement — 30x for a layer whose own was 5x)
     Returns (limit per field, the references' own ratio of that field's layer)."""
     rows = state_fields(ref_a, ref_b)
     layer = {}
     for name, ratio, *_ in rows:
         layer[_layer_of(name)] = max(layer.get(_layer_of(name), 0.0), ratio)
-    worst = max(layer.values())
     lim = {}
     for name, *_ in rows:
         own = layer[_layer_of(name)]
-        lim[name] = factor * worst if own > 1.0 else max(1.0, factor * own)
+        lim[name] = max(1.0, factor * own)
     return lim, {row[0]: layer[_layer_of(row[0])] for row in rows}
 
 
@@ -171,7 +185,7 @@ def assert_state_close_conditioned(got, ref32, ref64, what="state", factor=2.5):
     float32 run misses its float64 run by 30x the bound above in `Filter3.F1.filter`, 10x in `Filter3.F2.filter`, 5x in
     `dec.norm1.mean`, and sits inside the bound everywhere else; its 1-thread and 8-thread runs differ by as much).
     Only the layers in which the reference's own float32 run leaves the bound (3 of the 21 groups: the four statistics of a
-    normalisation layer, a filter, a style level) are widened — to `factor` times the reference's own worst miss; every
+    normalisation layer, a filter, a style level) are widened — each to `factor` times the reference's own miss IN THAT LAYER; every
     other layer is held to the regular bound (_field_limits).  Why 2.5 and not ~1: the miss is rounding noise amplified by
     the dynamic filters, not a property of an implementation — two direct-form float32 restatements of the same algorithm
     sit at 1.2x (torch conv2d) and 2.0x (nine numpy GEMMs) the reference's own worst field, and a run with EVERY

@@ -47,18 +47,19 @@ def _oracle_frame(oracle, o, padded, backend="torch"):
 
 
 def _pre_check(oracle, o, padded, got_pre, what):
-    """Full-size pre-clamp rule (tests/state_bounds.py: pre_full_size); returns the float64-accumulated oracle's image (the
-    image, too, is held to that evaluation: img_full_size)."""
-    ref32, _ = _oracle_frame(oracle, o, padded, "torch")
+    """Full-size pre-clamp rule (tests/state_bounds.py); returns (the float64-accumulated oracle's image, the float32 oracle's
+    image) for the image side of the rule."""
+    ref32, img32 = _oracle_frame(oracle, o, padded, "torch")
     ref64, img64 = _oracle_frame(oracle, o, padded, "torch64")
     worst, over, p, mean, t_worst, t_over = pre_full_size(got_pre, ref32, ref64, what)
     print("%s: error / bound vs the float64-accumulated oracle: worst %.3f, %d values over the bound, 99.99th percentile %.3f, mean %.4f (the float32 oracle itself: worst %.3f, %d over)"
           % (what, worst, over, p, mean, t_worst, t_over))
-    return img64
+    return img64, img32
 
 
-def _img_check(got, ref, what):
-    worst, over = img_full_size(got, ref, what)
+def _img_check(got, refs, what):
+    ref64, ref32 = refs if isinstance(refs, tuple) else (refs, None)
+    worst, over = img_full_size(got, ref64, what, ref32)
     print("%s: image max|d| %.4f grey levels, %d values beyond %.2f" % (what, worst, over, IMG_ATOL))
 
 
@@ -119,7 +120,7 @@ def test_config2_thirty_two_frames_per_launch_vs_oracle(pkg, weights, oracle, vi
             ref = _pre_check(oracle, o, frames[k], pres[k], "config 2 frame %d of 32, default kernel choice, pre-clamp" % k)
         else:
             ref = _oracle_frame(oracle, o, frames[k], "torch64")[1]
-        img_full_size(out[k], ref, "config 2 frame %d of 32" % k)
+        _img_check(out[k], ref, "config 2 frame %d of 32" % k)
     s.close()
 
 

@@ -164,7 +164,9 @@ def dec4_subsets(n_inputs=32):
         frames.append(f)
     print("\n# dec4 (every decoder weight x 4), %d inputs: conv_f43_k on layer subsets, worst pre-clamp error / bound per input vs the float64-accumulated oracle" % n_inputs)
     for name, layers in (("none (F(2x2,3x3) everywhere)", 0x000), ("encoder conv1_2 .. conv3_4", 0x07f), ("slice4/3/2.conv2", 0x380), ("slice4.conv2", 0x080), ("slice3.conv2", 0x100),
-                         ("slice2.conv2", 0x200), ("encoder + slice4.conv2", 0x0ff), ("encoder + slice4/3.conv2", 0x1ff), ("all ten", 0x3ff)):
+                         ("slice2.conv2", 0x200), ("encoder + slice4.conv2", 0x0ff), ("encoder + slice4/3.conv2", 0x1ff), ("all ten", 0x3ff),
+                         ("conv1_2", 0x001), ("conv2_1", 0x002), ("conv2_2", 0x004), ("conv3_1", 0x008), ("conv3_2", 0x010), ("conv3_3", 0x020), ("conv3_4", 0x040),
+                         ("conv1_2 .. conv2_2 + decoder", 0x387), ("conv3_1 .. conv3_4 + decoder", 0x3f8), ("conv1_2, conv2_1 + decoder", 0x383)):
         os.environ["RRV_F43_LAYERS"] = hex(layers)
         hip = pkg.Stylization(w, cuda=True); hip.set_state(g["state"]); hip.set_f43(2 if layers else 0)
         r = []
