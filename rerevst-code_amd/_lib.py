@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librerevst_hip.so")
+# RRV_LIB_PATH: another build of the same library (A/B runs of kernel variants: `python -m rerevst-code_amd.build` with extra -D flags)
+LIB_PATH = os.environ.get("RRV_LIB_PATH") or os.path.join(HERE, "librerevst_hip.so")
 STATE_FLOATS = 17536
 MAX_STYLES = 8
 

@@ -75,6 +75,11 @@
 #ifndef F43_UMID
 #define F43_UMID 0
 #endif
+// F43_U1: 1 = the U fragments come one position step at a time through a ring of four (read three steps ahead, counted
+// lgkmcnt per step) instead of six per MFMA run through two batches of six: 16 registers instead of 48
+#ifndef F43_U1
+#define F43_U1 0
+#endif
 // F43_L3: 1 = three lines of the input transform in lockstep instead of six (needs F43_KS; 48 op groups of three)
 #ifndef F43_L3
 #define F43_L3 1
@@ -481,6 +486,14 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
     f32x2 v[NPOS];                // transformed patch B^T d B of the chunk in flight: V[r][k] at index k*6 + r (raw piece (dy, dx) at dx*6 + dy)
     f32x4 ur[2][6];               // U fragments of two position batches: [ring slot][r] = {block 0: channels 2q, 2q+1; block 1: the same}
+    f32x4 u1[4];                  // F43_U1: ring of four position steps (step s = b*6 + r in slot s & 3)
+    auto read_u1 = [&](unsigned ub, auto sc) {      // U fragments of position step s (position r*6 + b) -> u1[s & 3]
+        constexpr int st = decltype(sc)::value, pos = (st % 6) * 6 + st / 6;
+        u1[st & 3] = lds_rd128<pos * 1024>(ub);
+    };
+    auto read_u1_first = [&](unsigned ub) {          // steps 0, 1, 2 of a chunk (behind the barrier that publishes its U block)
+        read_u1(ub, std::integral_constant<int, 0>{}); read_u1(ub, std::integral_constant<int, 1>{}); read_u1(ub, std::integral_constant<int, 2>{});
+    };
     // `hook(integral_constant<g>)` runs after op group g = 0..23 of the 24 (F43_DMA == 4: one LDS-DMA request each)
     auto full_transform = [&](f32x2 (&d)[NPOS], auto&& hook, auto&& mid) {
         // column passes: line dx = d[6 dx + 0..5]; then row passes: line r = d[r], d[6 + r], .., d[30 + r]
@@ -617,17 +630,20 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         static_for([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             // ---- gap b: U batch b is needed now; younger LDS reads = the patch column requested in run b-1's mini gap
-            if constexpr (b <= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else if constexpr (F43_RD2 == 1) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            if constexpr (b < 5) read_u_batch(ub, std::integral_constant<int, b + 1>{}, std::integral_constant<int, (b + 1) & 1>{});
+            if constexpr (F43_U1 == 0) {
+                if constexpr (b <= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else if constexpr (F43_RD2 == 1) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                if constexpr (b < 5) read_u_batch(ub, std::integral_constant<int, b + 1>{}, std::integral_constant<int, (b + 1) & 1>{});
+            }
             // ---- run b: 24 MFMAs, with ONE mini gap in the middle for the patch column (issued in the gap, behind the U reads, it
             // measured 1-2 % slower: profiles/r04_f43_store_study.txt) that also carries the chunk's LDS-DMA requests — wave w issues all of its 19 in
             // run w: the four waves of the CU share one address unit, requests issued at the same time queue behind each other
             static_for([&](auto rc) {
                 constexpr int r = decltype(rc)::value, pos = r * 6 + b;
                 constexpr int step = b * 6 + r;                  // issue order of the 36 position steps of a chunk
+                if constexpr (F43_U1 == 1 && step + 3 < NPOS) read_u1(ub, std::integral_constant<int, step + 3>{});
                 auto dma_req = [&](auto nc) {                    // request n of the chunk: 0..9 the halo, 10..18 the U block
                     constexpr int n = decltype(nc)::value;
                     if constexpr (n < G::RAW_IT) bufld16_rs(rs_r, rdst + (n * NT + wave * 64) * 16, asrc_of(n), rsoff);
@@ -663,8 +679,21 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                 }
                 constexpr bool AG = pos < NAG;
                 f32x4 (&ac)[2] = *[&]() -> f32x4 (*)[2] { if constexpr (AG) return &accA[pos]; else return &accV[pos - NAG]; }();
+                if constexpr (F43_U1 == 1) {
+                    // U(step) is complete when only the reads issued after it are outstanding: the U reads of the next
+                    // min(3, 35 - step) steps and — if a patch column went out in steps step-3 .. step — its pieces
+                    constexpr int NU = (35 - step) < 3 ? (35 - step) : 3;
+                    constexpr int PN = F43_RD2 == 1 ? 3 : 6;
+                    constexpr bool PATCH = (step >= 9) && ((step - 3) % 6 <= 3);      // some p in {step-3 .. step} with p % 6 == 3, p >= 9
+                    if constexpr (PATCH) {
+                        if (last) asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(NU) : "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(NU + PN) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(NU) : "memory");
+                    }
+                }
                 const f32x2 vv = v[b * 6 + r];
-                const f32x4 uu = ur[b & 1][r];
+                const f32x4 uu = F43_U1 == 1 ? u1[step & 3] : ur[b & 1][r];
                 // A operand = the patch (D row = tile), B operand = U (D column = cout row): see the epilogue for why
                 if constexpr (FIRST) { mfma_zero<AG>(ac[0], vv[0], uu[0]); mfma_zero<AG>(ac[1], vv[0], uu[2]); }
                 else { mfma_acc<AG>(ac[0], vv[0], uu[0]); mfma_acc<AG>(ac[1], vv[0], uu[2]); }
@@ -692,7 +721,10 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                 auto hk = dma_hook5(c + 1);
                 static_for([&](auto nc) { hk(nc); }, std::make_integer_sequence<int, G::RAW_IT + G::U_IT>{});
             }
-            auto rd_u0 = [&]() { read_u_batch(ubn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); };
+            auto rd_u0 = [&]() {
+                if constexpr (F43_U1 == 1) read_u1_first(ubn);
+                else read_u_batch(ubn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            };
             if constexpr (F43_UMID == 0) rd_u0();
             if constexpr (F43_TAIL == 1) {
                 if (!(ABL & 8)) f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return v[decltype(jc)::value * 6 + decltype(nc)::value]; });
@@ -708,7 +740,10 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     // first tiles of an item whose predecessor did not request them (the workgroup's first item)
     auto next_patch = [&]() {        // the item's raw(0) patch + first U batch -> registers, then V(0)
         static_for([&](auto dxc) { read_patch_col(std::integral_constant<int, 0>{}, dxc); }, std::make_integer_sequence<int, 6>{});
-        auto rd_u0 = [&]() { read_u_batch(offU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); };
+        auto rd_u0 = [&]() {
+            if constexpr (F43_U1 == 1) read_u1_first(offU);
+            else read_u_batch(offU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        };
         if constexpr (F43_UMID == 0) rd_u0();
         // every wave has read raw(0) before any wave's chunk 0 requests raw(2) into the same buffer
         if (!(ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
