@@ -45,9 +45,11 @@
 // profiles/r05_f43_timeline.txt): 0 all in the mini gap of run `wave` | 1 one per position step from step 0, all waves together |
 // 2 two per step, wave w in steps 5w..5w+9 | 3 one per step, wave w from step 4w | 4 inside the input transform that precedes the
 // chunk | 5 one burst right behind the chunk barrier (4 and 5: a VALU-only phase prices a request lower, but both compile with
-// VGPR spills and run 30 % slower).  The library ships 1.
+// VGPR spills and run 30 % slower) | 6 / 7 / 8 one request every 28/19, 36/19, 24/19 position steps (the CU's L2 -> LDS path
+// sustains 13-20 B/clock, the kernel needs 76 KB per ~7 000-clock chunk: requests issued faster than that stall the issuing wave).
+// The library ships 6 (+3.5-4.5 % over 1, +6-8 % over round 4's 0).
 #ifndef F43_DMA
-#define F43_DMA 1
+#define F43_DMA 6
 #endif
 // F43_TAIL: 0 barrier, first U batch, whole input transform | 1 column passes of the transform BEFORE the barrier (they need
 // nothing the barrier guards and absorb the waves' skew), row passes behind the first U batch's reads
@@ -651,6 +653,10 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                 };
                 if constexpr (F43_DMA == 1) {
                     if constexpr (step < G::RAW_IT + G::U_IT) { if (!(ABL & 1)) dma_req(std::integral_constant<int, step>{}); }
+                } else if constexpr (F43_DMA >= 6 && F43_DMA <= 8) {      // request n at step n * SPAN / 19: the 19 requests evenly over the first SPAN steps
+                    constexpr int SPAN = F43_DMA == 6 ? 28 : (F43_DMA == 7 ? 36 : 24), NREQ = G::RAW_IT + G::U_IT;
+                    constexpr int n = (step * NREQ + SPAN - 1) / SPAN;
+                    if constexpr (n < NREQ && (n * SPAN) / NREQ == step) { if (!(ABL & 1)) dma_req(std::integral_constant<int, n>{}); }
                 } else if constexpr (F43_DMA == 2) {
                     static_for([&](auto wc) {
                         constexpr int k = step - 5 * decltype(wc)::value;

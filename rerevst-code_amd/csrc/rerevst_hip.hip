@@ -469,7 +469,7 @@ bool use_f43(rrv_handle h, const ConvW& w, int B, int H, int W, int epi, bool up
     const double slabs = w.Cout / 32;
     const double items43 = (double)((H + 31) / 32) * ((W + 31) / 32) * B * slabs, items23 = (double)((H + 15) / 16) * ((W + 15) / 16) * B * slabs;
     const int ci = w.Cin >= 256 ? 2 : (w.Cin >= 128 ? 1 : 0);
-    static const double BASE_POOL[3] = {1.22, 1.25, 1.30}, BASE_RELU[3] = {1.19, 1.24, 1.28}, BASE_RES[3] = {1.21, 1.23, 1.28};
+    static const double BASE_POOL[3] = {1.33, 1.38, 1.41}, BASE_RELU[3] = {1.29, 1.35, 1.39}, BASE_RES[3] = {1.26, 1.33, 1.38};      // round 5 (profiles/r05_f43_timeline.txt, F43_DMA=6)
     const double base = (epi & E_POOL) ? BASE_POOL[ci] : (epi & E_RES_UPS) ? BASE_RES[ci] : BASE_RELU[ci];
     return rounds(items23) >= 1.04 * rounds(items43) * 4.0 / base;
 }
