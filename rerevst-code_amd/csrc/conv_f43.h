@@ -1,13 +1,14 @@
 // conv_f43.h — Winograd F(4x4,3x3) 3x3 convolution on the fp32 matrix cores: 36 multiplies per 4x4 outputs instead of
 // 144 (the F(2x2,3x3) kernel of conv_wino_split.h needs 64), for the same-resolution 3x3 layers with Cin, Cout >= 64
 // (vgg19.features convs, test/style_network_global.py:271-281; ResidualBlock.conv2 :104,119-122) when a launch carries
-// enough frames to fill the chip with 32x32-pixel work items (rerevst_hip.hip: conv(), F43_MIN_BATCH).
+// enough 32x32-pixel work items for its coarser rounds to win (rerevst_hip.hip: use_f43).
 //
-//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A,   6x6 patches four pixels apart, interpolation points 0, +-1, +-2, inf
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A,   6x6 patches four pixels apart, interpolation points 0, +-3/4, +-3/2, inf
 //
-// Exact in real arithmetic; in fp32 its rounding error is 3-6x that of F(2x2,3x3) (the transform matrices carry 4, 5, 8
-// and 1/24): measured against the reference goldens it leaves the pre-clamp output at <= 0.7 of the stated bound on the
-// layers it is used for (profiles/r04_parity_margin.txt), against 0.44 with F(2x2,3x3) everywhere.
+// Exact in real arithmetic.  In fp32 its rounding error is dominated by the accumulation over the input channels in the transform
+// domain; the balanced points (matrices below) cut it 2.4x against the textbook 0, +-1, +-2, inf: mean error 1.4x that of
+// F(2x2,3x3) at the BASELINE sizes, worst pre-clamp error / bound over 32 inputs x 3 well-conditioned weight sets <= 0.44
+// (F(2x2,3x3): <= 0.44; profiles/r05_parity_margin.txt, r05_fullsize_margin.txt).
 //
 // Why this form fits the machine where "36 positions x 32 couts x 16 channels" does not:
 //  * one wave per SIMD (4 waves, 512 registers each): a wave owns 16 tiles (8 x 32 output pixels) x 32 output channels
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
 
 // Weight transform U = G g G^T for F(4x4,3x3), packed [Cout/32][Cin/8][position 36][cout row 16][slot 4][block 2][2 floats] with
 // the 16-byte slots of a row XOR-swizzled by -(row>>2) & 3 (a lane-linear LDS-DMA copy lands as the conflict-free image):
-//   G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+//   G row j = (1, p_j, p_j^2) / prod_{l != j} (p_j - p_l) for the finite points 0, +a, -a, +b, -b (a = 3/4, b = 3/2), (0, 0, 1) for inf
 __global__ void pack_f43_k(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin) {
     const size_t total = (size_t)Cout * Cin * 36;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
