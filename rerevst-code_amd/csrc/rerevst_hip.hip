@@ -2020,9 +2020,19 @@ static void host_copy(void* dst, const void* src, size_t bytes) {
 }
 // caller buffers that are page-locked (rrv_host_alloc / rrv_host_register, or any hipHostMalloc'ed / registered range)
 // are DMA'd directly: no staging copy through the library's pinned buffers
+static std::mutex g_pin_mu;
+static std::map<const char*, size_t> g_pin_ranges;      // blocks handed out by rrv_host_alloc (the Python class's output pool): known page-locked without asking the runtime
 static bool is_pinned(const void* ptr, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_ranges.upper_bound((const char*)ptr);
+        if (it != g_pin_ranges.begin()) {
+            --it;
+            if ((const char*)ptr + bytes <= it->first + it->second) return true;
+        }
+    }
     hipPointerAttribute_t a;
-    for (const char* q : {(const char*)ptr, (const char*)ptr + (bytes ? bytes - 1 : 0)}) {
+    for (const char* q : {(const char*)ptr, (const char*)ptr + (bytes ? bytes - 1 : 0)}) {      // (a pageable array fails at its first byte: one query)
         if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
         if (a.type != hipMemoryTypeHost) return false;
     }
@@ -2664,9 +2674,16 @@ int rrv_last_compute_info(rrv_handle h, int* groups, int* group_size, size_t* wo
 int rrv_host_alloc(size_t bytes, void** out) {
     if (!out || !bytes) return RRV_E_ARG;
     *out = nullptr;
-    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? RRV_OK : RRV_E_NOMEM;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) return RRV_E_NOMEM;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_ranges[(const char*)*out] = bytes;
+    return RRV_OK;
 }
-int rrv_host_free(void* p) { return (p && hipHostFree(p) == hipSuccess) ? RRV_OK : RRV_E_ARG; }
+int rrv_host_free(void* p) {
+    if (!p) return RRV_E_ARG;
+    { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_ranges.erase((const char*)p); }
+    return hipHostFree(p) == hipSuccess ? RRV_OK : RRV_E_ARG;
+}
 int rrv_host_register(void* p, size_t bytes) {
     if (!p || !bytes) return RRV_E_ARG;
     return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? RRV_OK : RRV_E_HIP;
