@@ -10,6 +10,7 @@
 #include <thread>
 #include <stdio.h>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -2004,19 +2005,66 @@ static int host_sub(int B, int H, int W) {              // frames per sub-batch:
 }
 // copies between the caller's pageable arrays and the pinned staging buffers: first-touch page faults of a fresh
 // output array make a single thread slower than the GPU, so large copies are split over a few threads
+// A small persistent pool does the slices (round 5): creating std::threads per copy cost more than the 1.2 MB input frame of
+// a one-frame transfer() takes to copy, so that copy ran on one thread at ~10 GB/s = 0.12 ms of a 1.96 ms call.  The pool is
+// created on first use and never destroyed (its workers block on a condition variable; a static object torn down at exit
+// under them would be a crash); a second caller at the same time (another handle on another thread) copies by itself.
+namespace {
+struct CopyPool {
+    static constexpr int NW = 3;
+    std::mutex mu, call_mu;
+    std::condition_variable cv, done_cv;
+    struct Job { char* dst; const char* src; size_t n; } jobs[NW];
+    unsigned long gen = 0;
+    int pending = 0;
+    CopyPool() {
+        for (int i = 0; i < NW; ++i)
+            std::thread([this, i] {
+                unsigned long seen = 0;
+                for (;;) {
+                    Job j;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return gen != seen; });
+                        seen = gen;
+                        j = jobs[i];
+                    }
+                    if (j.n) memcpy(j.dst, j.src, j.n);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) done_cv.notify_one();
+                    }
+                }
+            }).detach();
+    }
+    // copies [slice, bytes) on the workers in nt - 1 slices while the caller copies [0, slice)
+    void run(char* dst, const char* src, size_t bytes, int nt, size_t slice) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int t = 0; t < NW; ++t) {
+                const size_t o = (size_t)(t + 1) * slice;
+                jobs[t] = Job{dst + o, src + o, (t + 1 < nt && o < bytes) ? (bytes - o < slice ? bytes - o : slice) : 0};
+            }
+            pending = NW;
+            ++gen;
+        }
+        cv.notify_all();
+        memcpy(dst, src, slice < bytes ? slice : bytes);
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+};
+}  // namespace
 static void host_copy(void* dst, const void* src, size_t bytes) {
-    constexpr size_t MIN_SLICE = (size_t)2 << 20;
+    constexpr size_t MIN_SLICE = (size_t)256 << 10;
     int nt = (int)(bytes / MIN_SLICE);
     if (nt > 4) nt = 4;
     if (nt < 2) { memcpy(dst, src, bytes); return; }
+    static CopyPool* const pool = new CopyPool();
+    std::unique_lock<std::mutex> call(pool->call_mu, std::try_to_lock);
+    if (!call.owns_lock()) { memcpy(dst, src, bytes); return; }
     const size_t slice = ((bytes / nt) + 4095) & ~(size_t)4095;
-    std::thread th[3];
-    for (int t = 1; t < nt; ++t) {
-        const size_t o = (size_t)t * slice, n = o >= bytes ? 0 : (bytes - o < slice ? bytes - o : slice);
-        th[t - 1] = std::thread([=] { if (n) memcpy((char*)dst + o, (const char*)src + o, n); });
-    }
-    memcpy(dst, src, slice < bytes ? slice : bytes);
-    for (int t = 1; t < nt; ++t) th[t - 1].join();
+    pool->run((char*)dst, (const char*)src, bytes, nt, slice);
 }
 // caller buffers that are page-locked (rrv_host_alloc / rrv_host_register, or any hipHostMalloc'ed / registered range)
 // are DMA'd directly: no staging copy through the library's pinned buffers
@@ -2198,7 +2246,7 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
         st.cap = fb;
     }
     const uint8_t* src = frame;
-    if (!in_pin) { memcpy(st.pin_in, frame, fb); src = st.pin_in; }
+    if (!in_pin) { host_copy(st.pin_in, frame, fb); src = st.pin_in; }
     // Four tickets may be open: each runs on its own (stream, workspace) with a quarter of the CUs per persistent grid, so
     // the frames run side by side instead of queueing behind each other's last partial round of work items (one frame
     // fills 1.56 - 12.5 rounds of 256 workgroups per layer; measured device-resident at 512 x 512, one frame per launch:

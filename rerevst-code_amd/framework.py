@@ -209,8 +209,10 @@ class Stylization():
         if not self.use_Global:
             self._chk(self._lib.rrv_transfer_frame_mode(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p)))
             return out
-        if style_weight is None:
-            self._chk(self._lib.rrv_transfer(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p)))
+        if style_weight is None:      # the reference's hot call: plain addresses (ctypes' data_as() objects cost ~10 us a call)
+            rc = self._lib.rrv_transfer(self._h, a.__array_interface__["data"][0], H, W, out.__array_interface__["data"][0])
+            if rc != 0:
+                self._chk(rc)
             return out
         w = (C.c_float * len(style_weight))(*[float(v) for v in style_weight])
         self._chk(self._lib.rrv_transfer_blend(self._h, a.ctypes.data_as(C.c_void_p), H, W, w, len(style_weight),
