@@ -212,8 +212,8 @@ def test_real_default_matches_reference(oracle, pkg, weights):
         assert_state_close(o.get_state(), g["state"])
         np.testing.assert_allclose(o.F_style["map"].sum(axis=(0, 1, 2)), g["style_map_chansum"], rtol=1e-4, atol=1e-3)
         padded = oracle.reflect_pad(decode_png(g["frame%d_png" % tid]), 576, 1152)
-        pre = o.transfer(padded, return_preclamp=True)[0][64:500, 64:1088]
-        out = oracle.tensor_to_image(o.transfer(padded, return_preclamp=True))[64:500, 64:1088]
+        y = o.transfer(padded, return_preclamp=True)
+        pre, out = y[0][64:500, 64:1088], oracle.tensor_to_image(y)[64:500, 64:1088]
     finally:
         oracle.set_conv_backend("numpy")
     assert_pre_close(pre[::4, ::4], g["pre_grid"])
@@ -243,8 +243,8 @@ def test_real_multistyle_matches_reference(oracle, pkg, weights):
         o.compute_norm()
         for k in range(2):
             assert_state_close(o.get_state(k), g["state%d" % k], "style %d" % k)
-        pre = o.transfer(feats[tid], wts, return_preclamp=True)[0][64:500, 64:1088]
-        out = o.transfer(feats[tid], wts)[64:500, 64:1088]
+        y = o.transfer(feats[tid], wts, return_preclamp=True)
+        pre, out = y[0][64:500, 64:1088], oracle.tensor_to_image(y)[64:500, 64:1088]
     finally:
         oracle.set_conv_backend("numpy")
     assert_pre_close(pre[::4, ::4], g["pre_grid"])
@@ -264,8 +264,8 @@ def test_real_frame_mode_matches_reference(oracle, pkg, weights):
         o = oracle.Stylization(weights, use_Global=False)
         o.prepare_style(decode_png(gin["style_png"]))
         padded = oracle.reflect_pad(decode_png(gin["frame%d_png" % tid]), 576, 1152)
-        pre = o.transfer(padded, return_preclamp=True)[0][64:500, 64:1088]
-        out = o.transfer(padded)[64:500, 64:1088]
+        y = o.transfer(padded, return_preclamp=True)
+        pre, out = y[0][64:500, 64:1088], oracle.tensor_to_image(y)[64:500, 64:1088]
     finally:
         oracle.set_conv_backend("numpy")
     assert_pre_close(pre[::4, ::4], g["pre_grid"])
