@@ -181,6 +181,22 @@ struct rrv_ctx {
     unsigned direct_layers = 0;       // RRV_DIRECT_LAYERS: encoder convs (bit i = vgg conv i: 1 conv1_2 .. 8 conv4_1) of the per-frame path that run the direct-form kernel
     int ms_group = 1;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
     int host_io = 0;                  // rrv_set_host_io: 0 = staged H2D / D2H copies, 1 = zero copy (kernels read / write page-locked host memory), 2 = input only, 3 = output only
+    // One-frame launches as hipGraphs (round 5): the 35 launches of a plain B = 1 transfer are captured once per (slot, geometry,
+    // buffers, kernel choice) and replayed — same kernels, same arguments, same bits; the dispatch gaps between the kernels
+    // of a frame shrink.  Measured: no gain (513 / 918 frames/s at 512 x 512 / 256 x 256 with, 513 / 925 without: the GPU never waits
+    // for a launch call), so it is OFF by default; RRV_GRAPH=1 switches it on (GPU suite green with it).  An entry is first SEEN (a normal run, which also allocates what is
+    // allocated lazily), captured on the second call with the same key and replayed from the third.
+    struct GraphKey {
+        int H = 0, W = 0; const void* d_in = nullptr; const void* d_out = nullptr; int f43_mode = 0; unsigned f43_layers = 0; int grid_share = 0;
+        const void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;      // workspace identity: encoder c11, decoder o2, split-K parts, pre-clamp tap
+        bool operator==(const GraphKey& o) const {
+            return H == o.H && W == o.W && d_in == o.d_in && d_out == o.d_out && f43_mode == o.f43_mode && f43_layers == o.f43_layers &&
+                   grid_share == o.grid_share && p0 == o.p0 && p1 == o.p1 && p2 == o.p2 && p3 == o.p3;
+        }
+    };
+    struct GraphEntry { GraphKey key; hipGraphExec_t exec = nullptr; unsigned stamp = 0; bool used = false; };
+    GraphEntry graphs[RRV_MAX_SLOTS][4];
+    bool use_graph = false;      // measured +-0 (profiles/r05_one_frame.txt): off unless RRV_GRAPH=1
     int n_cus = 256;
     int debug = 0;                    // rrv_set_debug / RRV_DEBUG: 1 = sync + check after every API call, 2 = after every kernel launch
     int fail_alloc_in = 0;            // rrv_debug_fail_alloc: the n-th next device allocation reports out-of-memory
@@ -952,6 +968,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     RCHK(enc_plan(h, e, B, H, W));
     RCHK(dec_plan(h, d, B, Ho, Wo));
     const float* st = h->cur->active;
+    auto body = [&]() -> int {
     if (feats) {  // one cached feature and one state set per image
         if (h->state_images != B) return fail(h, RRV_E_ARG, "transfer: per-image features need per-image state");
         for (int b = 0; b < B; ++b) {
@@ -1004,6 +1021,49 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     }
     RCHK(resblock_frame(h, B, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr));
     RCHK(run_last(h, d.o2, B, Ho, Wo, d_out, d.pre, pc, roi ? &wl : nullptr));
+    return RRV_OK;
+    };
+    // plain one-frame transfers replay a captured graph (see rrv_ctx::GraphEntry)
+    const bool graphable = h->use_graph && B == 1 && !feat && !feats && !pc && !h->profiling && !h->debug && !h->caller_sync &&
+                           h->state_images == 0 && h->cur == &h->sets[0];
+    if (!graphable) {
+        RCHK(body());
+    } else {
+        auto key_now = [&]() { return rrv_ctx::GraphKey{H, W, d_in, d_out, h->f43_mode, h->f43_layers, h->grid_share, e.c11.p, d.o2.p, d.dpart.p, d.pre}; };
+        const rrv_ctx::GraphKey key = key_now();
+        rrv_ctx::GraphEntry* ge = nullptr;
+        for (auto& g : h->graphs[slot]) if (g.used && g.key == key) ge = &g;
+        if (ge && ge->exec) {
+            ge->stamp = ++h->plan_clock;
+            HIPCHK(hipGraphLaunch(ge->exec, h->stream));
+            h->last_pre = d.pre; h->last_pre_H = Ho; h->last_pre_W = Wo; h->last_pre_B = 1;
+        } else if (ge) {                  // second sighting: capture, instantiate, replay
+            ge->stamp = ++h->plan_clock;
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            int rc = RRV_OK;
+            if (ok) {
+                rc = body();
+                ok = hipStreamEndCapture(h->stream, &graph) == hipSuccess && rc == RRV_OK && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok) {                    // no graph for this handle from here on; run the frame the ordinary way
+                (void)hipGetLastError();
+                ge->exec = nullptr; ge->used = false;
+                h->use_graph = false;
+                RCHK(body());
+            } else {
+                HIPCHK(hipGraphLaunch(ge->exec, h->stream));
+            }
+        } else {                          // first sighting: an ordinary run (allocates the split-K parts), then remember the key
+            RCHK(body());
+            rrv_ctx::GraphEntry* slot_e = &h->graphs[slot][0];
+            for (auto& g : h->graphs[slot]) { if (!g.used) { slot_e = &g; break; } if (g.stamp < slot_e->stamp) slot_e = &g; }
+            if (slot_e->exec) (void)hipGraphExecDestroy(slot_e->exec);
+            *slot_e = rrv_ctx::GraphEntry{key_now(), nullptr, ++h->plan_clock, true};
+        }
+    }
     if (h->caller_sync) {    // ... and whatever the caller queues next sees our output
         HIPCHK(hipEventRecord(h->slot_ev[slot], h->stream));
         HIPCHK(hipStreamWaitEvent(h->caller_stream, h->slot_ev[slot], 0));
@@ -1456,11 +1516,18 @@ int rrv_create(int device, rrv_handle* out) {
     if (const char* e = getenv("RRV_DIRECT_LAYERS")) h->direct_layers = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("RRV_F43")) h->f43_mode = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("RRV_DEBUG")) h->debug = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+    if (const char* e = getenv("RRV_GRAPH")) h->use_graph = atoi(e) != 0;
     *out = h;
     return RRV_OK;
 }
 
+static void free_graphs(rrv_handle h) {
+    for (auto& row : h->graphs)
+        for (auto& g : row) { if (g.exec) (void)hipGraphExecDestroy(g.exec); g = rrv_ctx::GraphEntry{}; }
+}
+
 static void free_plans(rrv_handle h) {
+    free_graphs(h);           // captured launches point into the plans
     for (auto& pair : h->enc_frame) for (EncPlan& e : pair) enc_free(e);
     enc_free(h->enc_add); enc_free(h->enc_style);
     for (auto& pair : h->dec) for (DecPlan& d : pair) dec_free(h, d);
