@@ -183,17 +183,19 @@ int rrv_set_multistyle_group(rrv_handle h, int frames);
 
 /* Kernel choice for the same-resolution 3x3 layers of the per-frame path that have a Winograd F(4x4,3x3) pack (conv_f43_k):
  * encoder conv1_2 .. conv3_4 (test/style_network_global.py:271-281) and the three ResidualBlock.conv2 (:104,119-122).
- * mode 0 = always F(2x2,3x3); 1 (default, also RRV_F43=) = F(4x4,3x3) where the launch has enough 32 x 32-pixel work items
- * for it to win (from four 640 x 640 frames per launch on every packed layer, from two 1152 x 1152 frames, from one where
- * the items are long; 1.07-1.20x per layer, +8 % frames/s at 512 x 512) — a rule on the layer, the batch and the frame size
- * only; 2 = always F(4x4,3x3).  The preparation pass (prepare_style / add / compute) and the frame mode always run
- * F(2x2,3x3).  RRV_F43_LAYERS (bit 0..6 = encoder conv1_2 .. conv3_4, bit 7..9 = slice4 / slice3 / slice2 .conv2; default
- * all ten) narrows the set.  F(4x4,3x3) rounds ~4x coarser than F(2x2,3x3): worst pre-clamp error over the reference
- * goldens 0.63 of the stated bound against 0.49 (profiles/r04_parity_margin.txt); in mode 1 a frame's low-order bits
- * therefore depend on how many frames share its launch; with a fixed mode every single-style entry delivers the same bits for
- * the same frame, and every mode is run-to-run deterministic.  The multi-style feature cache (rrv_generate_content_features)
- * and the grouped per-image-state launches (rrv_set_multistyle_group > 1) always run F(2x2,3x3), so in modes 1 / 2 a blended
- * rrv_transfer_blend of a frame and rrv_transfer_features of its cached feature differ by the kernels' rounding. */
+ * mode 0 = always F(2x2,3x3); 1 (default, also RRV_F43=) = F(4x4,3x3) where the launch geometry lets it win: a rule on the
+ * layer, the frames per launch, the frame size and the CUs the launch may use (the device's CU count under HSA_CU_MASK /
+ * RRV_CUS, divided by the grid share of the look-ahead tickets) — from four 640 x 640 frames per launch on every packed layer,
+ * from two 1152 x 1152 frames, from one where the items are long; 1.25-1.38x per layer, +16 % frames/s at 512 x 512;
+ * 2 = always F(4x4,3x3).  The preparation pass (prepare_style / add / compute) and the frame mode always run F(2x2,3x3).
+ * RRV_F43_LAYERS (bit 0..6 = encoder conv1_2 .. conv3_4, bit 7..9 = slice4 / slice3 / slice2 .conv2; default all ten) narrows
+ * the set.  In mode 1 a state whose dynamic filters are far from the O(1) scale (Frobenius norm above 4 sqrt 32: ill-conditioned
+ * in float32 whoever evaluates it) keeps the seven encoder layers on F(2x2,3x3).  F(4x4,3x3) makes 1.4x the rounding error of
+ * F(2x2,3x3): worst pre-clamp error over 32 inputs x 4 weight sets <= 0.73 of the stated bound in the default mode
+ * (profiles/r05_parity_margin.txt).  In mode 1 a frame's low-order bits therefore depend on how it was submitted; with a fixed
+ * mode every single-style entry delivers the same bits for the same frame, and every mode is run-to-run deterministic.  The
+ * one-frame feature cache entry (rrv_generate_content_features) and the grouped per-image-state launches
+ * (rrv_set_multistyle_group > 1) always run F(2x2,3x3); rrv_generate_content_features_batch follows the mode. */
 int rrv_set_f43(rrv_handle h, int mode);
 /* Capacity policy of the feature cache (default 64 GiB).  The reference spills every frame's feature to disk
  * (test.py:87-101, cache/%d.pt), so its video length is unbounded; here a cached feature costs 42 MB of HBM per

@@ -89,6 +89,7 @@ struct PrepPlan {
 
 struct StyleState {
     bool prepared = false, computed = false;
+    bool illcond = false;            // its dynamic filters are far from the O(1) scale (filter_conditioning): F(4x4,3x3) stays off the encoder
     float* blob = nullptr;           // RRV_STATE_FLOATS on device
     Tens map;                        // relu4_1 style map
     float* smean = nullptr;          // [6][32]: mean_{HW} F{1,2}.down_sample(normalised style map) of Filter1..3 (FilterPredictor's style half, constant per style)
@@ -177,6 +178,7 @@ struct rrv_ctx {
     int grid_share = 1;               // rrv_set_grid_share: persistent grids use 1/grid_share of the CUs
     int f43_mode = 1;                 // rrv_set_f43 / RRV_F43: layers with an F(4x4,3x3) pack run on conv_f43_k — 0 never, 1 where the launch has enough work items for it to win (use_f43), 2 always
     unsigned f43_layers = F43_DEFAULT_LAYERS;   // which of the packed layers may run on conv_f43_k (RRV_F43_LAYERS overrides: experiments / parity attribution)
+    bool illcond = false;             // some computed style's state is ill-conditioned (StyleState::illcond)
     bool f43_path = false;            // true inside transfer_device only: the preparation pass (prepare_style / add / compute, frame mode) always runs F(2x2,3x3)
     unsigned direct_layers = 0;       // RRV_DIRECT_LAYERS: encoder convs (bit i = vgg conv i: 1 conv1_2 .. 8 conv4_1) of the per-frame path that run the direct-form kernel
     int ms_group = 1;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
@@ -481,6 +483,10 @@ unsigned resident_wgs(rrv_handle h, int occ) {
 bool use_f43(rrv_handle h, const ConvW& w, int B, int H, int W, int epi, bool ups, int ksplit, bool per_image) {
     if (!h->f43_path || !w.pk_f43 || !((h->f43_layers >> w.f43_bit) & 1u) || ups || ksplit > 1 || per_image || h->f43_mode == 0) return false;
     if (h->f43_mode == 2) return true;
+    // Ill-conditioned state (filter_conditioning): the decoder multiplies whatever error the encoder makes, and F(4x4,3x3) on the
+    // seven encoder layers makes 1.4x the error of F(2x2,3x3) (profiles/r05_parity_margin.txt: the x4-decoder weight set goes from
+    // 0.73 to 1.42 of the pre-clamp bound with them, stays at 0.73 with the three decoder layers alone): the rule keeps them off.
+    if (h->illcond && w.f43_bit < 7) return false;
     const double R = (double)resident_wgs(h, 1);      // persistent workgroups of this launch: one per CU the handle may use (rrv_create: device CU count under HSA_CU_MASK / RRV_CUS; rrv_set_grid_share / look-ahead tickets: a share of them)
     auto rounds = [&](double items) { return std::ceil(items / R); };
     const double slabs = w.Cout / 32;
@@ -719,6 +725,25 @@ int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
     hipLaunchKernelGGL(fold_up_k, dim3((512 * 32 * 9 + 255) / 256), dim3(256), 0, h->stream, F2, (const float*)wu.raw, fu.raw, 512);
     HIPCHK(hipGetLastError());
     RCHK(pack_wino(h, fu));          // 32 input channels = two 16-channel chunks per work item
+    return RRV_OK;
+}
+
+// Conditioning of a style's saved state, read off its six dynamic 32 x 32 filters (FilterPredictor outputs): every state seen
+// so far with seeded or real inputs has filters of Frobenius norm 5.5 .. 5.8 (~ sqrt 32: near-orthogonal), while the weight set
+// built to be ill-conditioned in float32 (every decoder weight x 4; the reference's own float32 run misses its float64 run by
+// 30x the state bound) reaches 2e2 .. 3e6.  Above 4 x sqrt 32 the state counts as ill-conditioned.
+int filter_conditioning(rrv_handle h, StyleState& S) {
+    std::vector<float> f(6 * 1024);
+    HIPCHK(hipMemcpy(f.data(), S.blob + SL.filt[0], f.size() * sizeof(float), hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    for (int k = 0; k < 6; ++k) {
+        double ss = 0.0;
+        for (int i = 0; i < 1024; ++i) ss += (double)f[k * 1024 + i] * f[k * 1024 + i];
+        worst = std::sqrt(ss) > worst ? std::sqrt(ss) : worst;
+    }
+    S.illcond = !(worst <= 4.0 * std::sqrt(32.0));      // (NaN counts as ill-conditioned)
+    h->illcond = false;
+    for (StyleState& t : h->styles) h->illcond = h->illcond || (t.computed && t.illcond);
     return RRV_OK;
 }
 
@@ -1174,6 +1199,7 @@ int compute_style(rrv_handle h, int sid, const Tens& content) {
     (void)hipStreamSynchronize(h->stream);
     prep_free(h);
     if (rc == RRV_OK) S.computed = true;
+    if (rc == RRV_OK) rc = filter_conditioning(h, S);
     return rc;
 }
 
@@ -1434,6 +1460,7 @@ int compute_style_streaming(rrv_handle h, int sid, int G) {
     for (int f = 0; f < 3; ++f) tfree(&h->stream_u[f]);
     h->active_src = -1;
     if (rc == RRV_OK) S.computed = true;
+    if (rc == RRV_OK) rc = filter_conditioning(h, S);
     return rc;
 }
 
@@ -1788,6 +1815,7 @@ int rrv_clean(rrv_handle h) {
     h->pend_n = 0;
     h->patch_h = h->patch_w = h->add_H = h->add_W = 0;
     for (StyleState& s : h->styles) s.computed = false;
+    h->illcond = false;
     h->active_src = -1;
     h->user_style = -1;
     return RRV_OK;
@@ -1894,6 +1922,7 @@ int rrv_set_state(rrv_handle h, const float* in, int n, int sid) {
     RCHK(sync_all(h));
     HIPCHK(hipMemcpy(S.blob, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     S.computed = true;
+    RCHK(filter_conditioning(h, S));
     // the style set last is the one the plain transfer entries use next: re-fold now unless another style's folded
     // state is live (after a blend, -2, nothing of the old fold is worth keeping either)
     if (h->active_src == sid || h->active_src < 0) { h->active_src = -1; RCHK(activate_state(h, sid)); }
@@ -1981,6 +2010,7 @@ int rrv_broadcast_state(rrv_handle h, void* comm, int root, int my_rank, int sid
     HIPCHK(hipStreamSynchronize(h->streams[0]));
     if (my_rank != root) {
         S.computed = true;
+        RCHK(filter_conditioning(h, S));
         if (h->active_src == sid || h->active_src < 0) { h->active_src = -1; RCHK(activate_state(h, sid)); }
     }
     return RRV_OK;

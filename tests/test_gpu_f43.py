@@ -233,3 +233,36 @@ def test_default_choice_is_the_faster_one_for_the_cus_a_launch_gets(case):
             pytest.skip("HSA_CU_MASK is not honoured on this box (masked %.2f ms, unmasked %.2f ms)" % (ms["0"], full["0"]))
     print("%s: F(2x2,3x3) everywhere %.3f ms, default rule %.3f ms, conv_f43_k everywhere %.3f ms" % (case, ms["0"], ms["1"], ms["2"]))
     assert ms["1"] <= 1.05 * min(ms["0"], ms["2"]), (case, ms)
+
+
+def test_ill_conditioned_state_keeps_f43_off_the_encoder(pkg, oracle):
+    """use_f43's conditioning guard (rerevst_hip.hip: filter_conditioning): a state whose dynamic filters are far from the
+    O(1) scale — the x4-decoder weight set, whose saved state the reference's own float32 run misses by 30x — runs the seven
+    ENCODER layers in F(2x2,3x3) in the default mode (the three decoder layers keep F(4x4,3x3): profiles/r05_parity_margin.txt);
+    a well-conditioned state on the same handle gets all ten layers back."""
+    g4, g0 = load_golden("global_a_dec4"), load_golden("global_a")
+    frames = np.stack([oracle.reflect_pad(pkg.synth_frame(900 + i, 128, 128, kind="noise"), 256, 256) for i in range(16)])
+    w = pkg.weight_variant("dec4")
+    a = pkg.Stylization(w, cuda=True)                         # default mode: the rule picks conv_f43_k on every packed layer at 16 x 256 x 256
+    a.set_state(g4["state"])
+    got_ill = np.array(a.transfer_batch(frames))
+    a.set_state(g0["state"])
+    got_ok = np.array(a.transfer_batch(frames))
+    a.close()
+    old = os.environ.get("RRV_F43_LAYERS")
+    try:
+        os.environ["RRV_F43_LAYERS"] = "0x380"                # decoder layers only, forced
+        b = pkg.Stylization(w, cuda=True)
+        b.set_f43(2); b.set_state(g4["state"])
+        np.testing.assert_array_equal(got_ill, b.transfer_batch(frames))
+        b.close()
+        os.environ["RRV_F43_LAYERS"] = "0x3ff"                # all ten, forced
+        c = pkg.Stylization(w, cuda=True)
+        c.set_f43(2); c.set_state(g0["state"])
+        np.testing.assert_array_equal(got_ok, c.transfer_batch(frames))
+        c.close()
+    finally:
+        if old is None:
+            os.environ.pop("RRV_F43_LAYERS", None)
+        else:
+            os.environ["RRV_F43_LAYERS"] = old

@@ -177,6 +177,16 @@ def dec4_subsets(n_inputs=32):
         r = np.array(r)
         print("%-32s max %.3f, 99th pct %.3f, median %.3f, inputs over 0.8: %2d" % (name, r.max(), np.percentile(r, 99), np.median(r), int((r > 0.8).sum())), flush=True)
     os.environ.pop("RRV_F43_LAYERS", None)
+    # the library's DEFAULT (mode 1) at sixteen frames per launch: the rule would pick all ten layers here, the conditioning
+    # guard of use_f43 (filter_conditioning: this state's dynamic filters are 2e2 .. 3e6 in norm against ~5.7) keeps the encoder on F(2x2,3x3)
+    hip = pkg.Stylization(w, cuda=True); hip.set_state(g["state"])
+    r = []
+    for f, ref in zip(frames, refs):
+        hip.transfer_batch([f] * 16)
+        r.append(T.pre_worst(hip.preclamp(256, 256), ref)[0])
+    hip.close()
+    r = np.array(r)
+    print("%-32s max %.3f, 99th pct %.3f, median %.3f, inputs over 0.8: %2d" % ("DEFAULT rule, 16 per launch", r.max(), np.percentile(r, 99), np.median(r), int((r > 0.8).sum())), flush=True)
 
 
 if "--dec4-subsets" in sys.argv:
