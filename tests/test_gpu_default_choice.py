@@ -87,14 +87,14 @@ def test_headline_sixteen_white_noise_frames_per_launch_vs_oracle(headline, pkg,
 def test_ragged_batch_in_the_default_mode_every_frame_vs_oracle(headline, pkg, oracle, video):
     """19 frames in one rrv_transfer_batch call = sub-batches of 16 and 3: the tail runs other kernels than the body (the
     rule follows the launch geometry): the body's frames are bit-identical to the sixteen-frame call of the test above, every
-    tail frame meets the oracle in pre-clamp and image, two more body frames in the image."""
+    tail frame meets the oracle in pre-clamp and image, one more body frame in the image."""
     s, o = headline
     frames = np.stack([video.reflect_pad(pkg.synth_frame(1 + i, 512, 512, kind="noise"), 640, 640) for i in range(19)])
     out = np.array(s.transfer_batch(frames))
     tail_pre = [np.array(s.preclamp(640, 640, image=k)) for k in range(3)]
     body = np.array(s.transfer_batch(frames[:16]))
     np.testing.assert_array_equal(out[:16], body)           # a sub-batch's bits do not depend on the rest of the call
-    for k in (3, 11, 16, 17, 18):         # (frames 0, 7, 15 of the body: the headline test above — the same launch, the same bits)
+    for k in (11, 16, 17, 18):            # (frames 0, 7, 15 of the body: the headline test above — the same launch, the same bits)
         if k >= 16:
             ref = _pre_check(oracle, o, frames[k], tail_pre[k - 16], "tail frame %d of a 19-frame call, pre-clamp" % k)
         else:
@@ -115,7 +115,7 @@ def test_config2_thirty_two_frames_per_launch_vs_oracle(pkg, weights, oracle, vi
     pres = {k: np.array(s.preclamp(384, 384, image=k)) for k in (0, 12, 30)}
     with fixed_kernels(s):
         assert not np.array_equal(s.transfer_batch(frames), out)
-    for k in range(0, 32, 3):            # every third frame of the launch (a frame's arithmetic does not depend on its place in it)
+    for k in range(0, 32, 6):            # every sixth frame of the launch (a frame's arithmetic does not depend on its place in it)
         if k in pres:
             ref = _pre_check(oracle, o, frames[k], pres[k], "config 2 frame %d of 32, default kernel choice, pre-clamp" % k)
         else:
