@@ -175,10 +175,11 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* style_weigh
  * two (stream, workspace, blended-state) sets and the D2H copy of one frame overlaps the next frame's kernels. */
 int rrv_transfer_features_batch(rrv_handle h, const int* feature_ids, const float* style_weight, int n, int n_styles, float* out_bgr);
 int rrv_release_features(rrv_handle h);
-/* Frames per launch sequence of rrv_transfer_features_batch (1..4, default 1).  With more than one, every image of a
+/* Frames per launch sequence of rrv_transfer_features_batch (1..4, default 2).  With more than one, every image of a
  * launch carries its own blended state set (per-image normalisation parameters and folded KernelFilter weights), which
- * widens the grids of the small relu4_1-level layers; results are bit-identical for every setting.  Measured at
- * 1152 x 1152 x 4 styles: 340 / 339 / 330 frames/s for 1 / 2 / 4 (the two-stream pipeline already fills the chip). */
+ * widens the grids of the small relu4_1-level layers and lets the kernel choice (rrv_set_f43) count the group's frames;
+ * with a fixed kernel mode the results are bit-identical for every setting.  Measured at 1152 x 1152 x 4 styles in the
+ * default mode (round 5, conv_f43_k with per-image parameters): 371 / 382 / 381 frames/s for 1 / 2 / 4. */
 int rrv_set_multistyle_group(rrv_handle h, int frames);
 
 /* Kernel choice for the same-resolution 3x3 layers of the per-frame path that have a Winograd F(4x4,3x3) pack (conv_f43_k):
@@ -194,8 +195,8 @@ int rrv_set_multistyle_group(rrv_handle h, int frames);
  * F(2x2,3x3): worst pre-clamp error over 32 inputs x 4 weight sets <= 0.73 of the stated bound in the default mode
  * (profiles/r05_parity_margin.txt).  In mode 1 a frame's low-order bits therefore depend on how it was submitted; with a fixed
  * mode every single-style entry delivers the same bits for the same frame, and every mode is run-to-run deterministic.  The
- * one-frame feature cache entry (rrv_generate_content_features) and the grouped per-image-state launches
- * (rrv_set_multistyle_group > 1) always run F(2x2,3x3); rrv_generate_content_features_batch follows the mode. */
+ * one-frame feature cache entry (rrv_generate_content_features) always runs F(2x2,3x3); rrv_generate_content_features_batch
+ * and the grouped per-image-state launches (rrv_set_multistyle_group > 1) follow the mode. */
 int rrv_set_f43(rrv_handle h, int mode);
 /* Capacity policy of the feature cache (default 64 GiB).  The reference spills every frame's feature to disk
  * (test.py:87-101, cache/%d.pt), so its video length is unbounded; here a cached feature costs 42 MB of HBM per

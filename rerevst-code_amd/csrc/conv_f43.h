@@ -453,15 +453,18 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         for (int it = 0; it < G::RAW_IT; ++it) bufld16_rs(rs, rdst + (it * NT + wave * 64) * 16, asrc_of(it), chunk * 32);
     };
     char* const par = smem + 2 * RAW_BYTES + 2 * U_BYTES;
-    auto stage_params = [&](int ntile) {
+    // img: the item's image.  Per-image state (ConvP::par_bstride != 0, the grouped multi-style decoder): image b reads its
+    // saved statistics / style affine at n1 / n2 / sty + b * par_bstride; bias and weights are shared by the layers this kernel serves.
+    auto stage_params = [&](int ntile, int img) {
         if (wave < 2) {
             const int e = tid;
             const int row = e >> 3, col = (e & 7) * 4;
             const float* src = p.bias;
             int off = ntile * 32 + col;
-            if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off += (EPI & E_NORM1) ? (row - 1) * p.Cout : 0; }
-            if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off += (EPI & E_NORM2) ? (row - 5) * p.Cout : 0; }
-            if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off += (EPI & E_NORM2) ? (row - 9) * p.Cout : 0; }
+            const int pb = img * p.par_bstride;
+            if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off += (EPI & E_NORM1) ? (row - 1) * p.Cout + pb : 0; }
+            if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off += (EPI & E_NORM2) ? (row - 5) * p.Cout + pb : 0; }
+            if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off += (EPI & E_NORM2) ? (row - 9) * p.Cout + pb : 0; }
             if (row > 10) { src = p.bias; off = ntile * 32; }
             glds16(src + off, par + wave * 1024);
         }
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
 #endif
     constexpr int NAG = F43_NAG;
     f32x4 accA[NAG][2], accV[NPOS - NAG][2];
-    int par_ntile = -1;
+    int par_ntile = -1, par_img = -1;
     long long tl[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;      // ABL & 16 (microbench): cycles per phase, summed over items
     auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
     f32x2 v[NPOS];                // transformed patch B^T d B of the chunk in flight: V[r][k] at index k*6 + r (raw piece (dy, dx) at dx*6 + dy)
@@ -766,8 +769,8 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         stage_raw(0);
         stage_u(0);
         stage_raw(1);
-        stage_params(cur.nt);
-        par_ntile = cur.nt;
+        stage_params(cur.nt, cur.b);
+        par_ntile = cur.nt; par_img = cur.b;
         __syncthreads();
         next_patch();
         __syncthreads();      // round-3 fix, as in the library kernels: raw(0) is read by every wave before the first chunk's LDS-DMA reuses its buffer
@@ -780,10 +783,10 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         in_n = have_nxt ? in_of(nxt) : in_t;
         w_n = have_nxt ? w_of(nxt) : w_t;
         lim_n = have_nxt ? lim_of(nxt) : lim_t;
-        if (par_ntile != e_ntile) {
+        if (par_ntile != e_ntile || (p.par_bstride != 0 && par_img != e_b)) {
             __syncthreads();
-            stage_params(e_ntile);
-            par_ntile = e_ntile;
+            stage_params(e_ntile, e_b);
+            par_ntile = e_ntile; par_img = e_b;
         }
         tick(0);                                  // item setup
         chunk_body(0, std::integral_constant<int, 0>{}, std::true_type{}, false);

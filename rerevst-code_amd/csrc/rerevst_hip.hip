@@ -181,7 +181,7 @@ struct rrv_ctx {
     bool illcond = false;             // some computed style's state is ill-conditioned (StyleState::illcond)
     bool f43_path = false;            // true inside transfer_device only: the preparation pass (prepare_style / add / compute, frame mode) always runs F(2x2,3x3)
     unsigned direct_layers = 0;       // RRV_DIRECT_LAYERS: encoder convs (bit i = vgg conv i: 1 conv1_2 .. 8 conv4_1) of the per-frame path that run the direct-form kernel
-    int ms_group = 1;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
+    int ms_group = 2;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
     int host_io = 0;                  // rrv_set_host_io: 0 = staged H2D / D2H copies, 1 = zero copy (kernels read / write page-locked host memory), 2 = input only, 3 = output only
     // One-frame launches as hipGraphs (round 5): the 35 launches of a plain B = 1 transfer are captured once per (slot, geometry,
     // buffers, kernel choice) and replayed — same kernels, same arguments, same bits; the dispatch gaps between the kernels
@@ -501,7 +501,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     const ConvW& w = *c.w;
     const ConvKey* k = nullptr;
     bool wino = false;
-    bool f43 = !c.direct && use_f43(h, w, c.B, c.H, c.W, c.epi, c.ups, c.ksplit, (c.par_bstride | c.bias_bstride) != 0 || c.w_bstride != 0) &&
+    bool f43 = !c.direct && use_f43(h, w, c.B, c.H, c.W, c.epi, c.ups, c.ksplit, c.bias_bstride != 0 || c.w_bstride != 0) &&      // per-image PARAMETERS are conv_f43_k's too (par_bstride); per-image bias / weights (the folded KernelFilter convs) are not
                !((c.wy0 | c.wx0 | c.wy1 | c.wx1) & 31);      // 32 x 32 pixel work items: a window must be aligned to them
     if (f43) {
         f43 = false;
@@ -580,7 +580,7 @@ int conv(rrv_handle h, const ConvCall& c) {
                                 (fuse_sc ? (double)c.B * c.in->H * c.in->W * w.Cout + (double)w.Cout * cin : 0.0));
     hipStream_t s = h->stream;
     ConvFn fn = k->fn;
-    if (wino && (c.par_bstride | c.bias_bstride || c.w_bstride)) {      // per-image state is a separate instantiation of the transform-domain kernels
+    if (wino && !f43 && (c.par_bstride | c.bias_bstride || c.w_bstride)) {      // per-image state is a separate instantiation of the F(2x2,3x3) / upsample-fused kernels (conv_f43_k reads par_bstride itself)
         if (!k->fn_img) return fail(h, RRV_E_ARG, "conv: this layer has no per-image-state kernel");
         fn = k->fn_img;
     }
@@ -1036,7 +1036,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         const Win crop{pc->top, pc->left, pc->top + pc->src_H, pc->left + pc->src_W};
         wl = grow(crop, 0);        // conv_last output tiles
         wo = grow(crop, 1);        // slice2.conv2 output feeding them
-        if (use_f43(h, h->conv["Decoder.slice2.conv2"], B, Ho, Wo, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2, false, 0, h->state_images != 0)) {      // 32 x 32 pixel work items: round the window out to them
+        if (use_f43(h, h->conv["Decoder.slice2.conv2"], B, Ho, Wo, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2, false, 0, false)) {      // 32 x 32 pixel work items: round the window out to them
             const int lh = (Ho + 31) & ~31, lw = (Wo + 31) & ~31;
             wo = Win{wo.y0 & ~31, wo.x0 & ~31, (wo.y1 + 31) & ~31, (wo.x1 + 31) & ~31};
             if (wo.y1 > lh) wo.y1 = lh;
@@ -2613,7 +2613,7 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
     RCHK(sync_all(h));
     const size_t npx = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
     const bool out_pin = is_pinned(out, (size_t)n * npx * sizeof(float));
-    int G = h->ms_group;       // rrv_set_multistyle_group (default 1: measured 340 / 339 / 330 frames/s for 1 / 2 / 4 at 1152 x 1152 x 4 styles)
+    int G = h->ms_group;       // rrv_set_multistyle_group (default 2: 371 / 382 / 381 frames/s for 1 / 2 / 4 at 1152 x 1152 x 4 styles, conv_f43_k with per-image parameters)
     if (G > n) G = n;
     struct Group { int first, count; };
     std::vector<Group> groups;

@@ -64,7 +64,8 @@ def test_multistyle_s4_matches_reference(pkg, weights, oracle):
 def test_config5_full_size_1024_four_styles_vs_oracle(pkg, weights, oracle):
     """BASELINE config 5 at full size in the library's DEFAULT kernel choice (what bench.py --multistyle 4 times): 1024x1024
     frames padded to 1152x1152, 4 styles resized to 384x384, the driver's weight ramp, cached features, rrv_transfer_features_batch
-    (one frame per launch: the three ResidualBlock.conv2 run conv_f43_k with the blended state).  The oracle receives the HIP
+    (the library's default of two frames per launch, each with its own blended state: the three ResidualBlock.conv2 run
+    conv_f43_k with per-image parameters).  The oracle receives the HIP
     state blobs (their parity is the golden test above) and runs the same blended decoder on its own encoder output."""
     V = importlib.import_module("rerevst-code_amd.video")
     S = 4
@@ -83,7 +84,7 @@ def test_config5_full_size_1024_four_styles_vs_oracle(pkg, weights, oracle):
     wts = [V.ramp_weights(37, 300, S), V.ramp_weights(150, 300, S, blend="all")]      # two styles active / all four (the bench's ramp)
     assert abs(sum(wts[0]) - 1.0) < 1e-12 and sum(1 for w in wts[0] if w > 0) == 2 and all(w > 0 for w in wts[1])
     many = np.array(s.transfer_many([feats[1], feats[0]], wts))
-    pre = s.preclamp(1152, 1152)                          # the last launch: frame 0 with all four styles
+    pre = s.preclamp(1152, 1152, image=1)                 # the launch's second image: frame 0 with all four styles
     with fixed_kernels(s):
         pinned = np.array(s.transfer_many([feats[1], feats[0]], wts))
     assert not np.array_equal(pinned, many)               # the default really ran conv_f43_k here
@@ -105,10 +106,11 @@ def test_config5_full_size_1024_four_styles_vs_oracle(pkg, weights, oracle):
         img_full_size(pinned[k], oracle.tensor_to_image(ref64[None]), "config 5 frame %d, F(2x2,3x3) everywhere" % k)
     # decoder-only on the cached feature == the one-frame entry; the full path on the same padded frame (its encoder may run
     # F(4x4,3x3), the cached features never do) gives the same picture, and the same to 1e-3 for a fixed kernel choice
-    np.testing.assert_array_equal(s.transfer(feats[1], wts[0]), many[0])
+    assert np.abs(s.transfer(feats[1], wts[0]) - many[0]).max() <= IMG_ATOL      # (one frame per launch: the kernel choice may differ)
     full = pkg.Stylization.transfer(s, padded[1], style_weight=wts[0])
     assert np.abs(full - many[0]).max() <= IMG_ATOL
     with fixed_kernels(s):
+        np.testing.assert_array_equal(s.transfer(feats[1], wts[0]), pinned[0])
         full = pkg.Stylization.transfer(s, padded[1], style_weight=wts[0])
         assert np.abs(full - s.transfer(s.generate_content_features(padded[1]), wts[0])).max() <= 1e-3
     s.close()
@@ -226,7 +228,7 @@ def test_multistyle_batched_transfer_equals_per_frame(pkg, weights, oracle):
     s.compute_norm()
     wts = [V.ramp_weights(i, 7, 4) for i in range(7)]
     wts[3] = [float(v) for v in g["weights"]]
-    s.set_f43(0)          # grouped launches (per-image state) are F(2x2,3x3) in every mode: a bit-identity test needs ONE family
+    s.set_f43(0)          # a bit-identity test needs ONE kernel family (the default mode chooses by the frames per launch)
     single = np.stack([s.transfer(feats[i], wts[i]) for i in range(7)])
     many = s.transfer_many(feats, wts)
     np.testing.assert_array_equal(many, single)
@@ -241,6 +243,14 @@ def test_multistyle_batched_transfer_equals_per_frame(pkg, weights, oracle):
         np.testing.assert_array_equal(s.transfer_many(feats, wts), single)
         np.testing.assert_array_equal(s.transfer_many(feats, wall), single_all)
     s.set_multistyle_group(1)
+    s.set_f43(2)          # conv_f43_k on the decoder's conv2 layers reads per-image parameters itself (ConvP::par_bstride): same bits in groups
+    single43 = np.stack([s.transfer(feats[i], wall[i]) for i in range(7)])
+    assert not np.array_equal(single43, single_all) and np.abs(single43 - single_all).max() <= 0.05
+    for grp in (2, 4):
+        s.set_multistyle_group(grp)
+        np.testing.assert_array_equal(s.transfer_many(feats, wall), single43)
+    s.set_multistyle_group(1)
+    s.set_f43(0)
     one = pkg.Stylization.transfer(s, frames[1])                       # plain transfer: style 0's own state again
     ref0 = pkg.Stylization.transfer(s, frames[1], style_weight=[1.0, 0.0, 0.0, 0.0])
     assert np.abs(one - ref0).max() <= 1e-3
@@ -274,9 +284,10 @@ def test_multistyle_command_line_driver_end_to_end(tmp_path, pkg, weights):
 def test_random_sequence_of_multistyle_entries_is_bit_exact():
     """tools/soak_multistyle.py, short form: transfer_many over random features / weights / group sizes / pipeline depths,
     single transfers and blended full-frame transfers in between — every batched frame bit-identical to the per-feature
-    transfer() (state sets per slot and per image, blends and folds on two streams)."""
+    transfer() (state sets per slot and per image, blends and folds on two streams), within one kernel family."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("soak_multistyle", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_multistyle.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    mod.run(iters=600, seed=5, verbose=False)
+    mod.run(iters=400, seed=5, verbose=False, mode=0)
+    mod.run(iters=300, seed=6, verbose=False, mode=2)       # conv_f43_k with per-image parameters in the grouped launches
