@@ -361,7 +361,7 @@ def main():
     else:
         model = pkg.Stylization(weights, cuda=True, device=local)
     model.set_pipeline(args.pipeline)
-    MS_GROUP = int(os.environ.get("RRV_BENCH_MS_GROUP", "2"))      # (experiment knob; 2 =) frames per launch sequence of rrv_transfer_features_batch (the library's default, set explicitly: what config.sub_batch reports)
+    MS_GROUP = int(os.environ.get("RRV_BENCH_MS_GROUP", "0")) or max(1, min(16, (16 * 640 * 640) // (P * P)))      # (experiment knob; default =) frames per launch sequence of rrv_transfer_features_batch (the library's rule, set explicitly: what config.sub_batch reports)
     if NS:
         model.set_multistyle_group(MS_GROUP)
     if os.environ.get("RRV_BENCH_GRID_SHARE"):       # experiment knob: every launch takes 1/n of the CUs (DESIGN 4 "One frame per call")

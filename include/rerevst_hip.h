@@ -175,11 +175,13 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* style_weigh
  * two (stream, workspace, blended-state) sets and the D2H copy of one frame overlaps the next frame's kernels. */
 int rrv_transfer_features_batch(rrv_handle h, const int* feature_ids, const float* style_weight, int n, int n_styles, float* out_bgr);
 int rrv_release_features(rrv_handle h);
-/* Frames per launch sequence of rrv_transfer_features_batch (1..4, default 2).  With more than one, every image of a
- * launch carries its own blended state set (per-image normalisation parameters and folded KernelFilter weights), which
- * widens the grids of the small relu4_1-level layers and lets the kernel choice (rrv_set_f43) count the group's frames;
- * with a fixed kernel mode the results are bit-identical for every setting.  Measured at 1152 x 1152 x 4 styles in the
- * default mode (round 5, conv_f43_k with per-image parameters): 371 / 382 / 381 frames/s for 1 / 2 / 4. */
+/* Frames per launch sequence of rrv_transfer_features_batch: 1..16, or 0 (default) = by the frame size, ~6.6 Mpixel per
+ * launch as in the single-style host entries (4 at 1152 x 1152, 16 at 640 x 640 and below).  With more than one, every
+ * image of a launch carries its own blended state set (per-image normalisation parameters and folded KernelFilter
+ * weights), which widens every layer's grid and lets the kernel choice (rrv_set_f43) count the group's frames; with a
+ * fixed kernel mode the results are bit-identical for every setting.  Measured with four styles in the default mode
+ * (round 5, conv_f43_k with per-image parameters), frames/s for 1 / 2 / 4 per launch: 1152 x 1152 371 / 382 / 381,
+ * 640 x 640 941 / 1070 / 1167, 384 x 384 1750 / 2163 / 2590. */
 int rrv_set_multistyle_group(rrv_handle h, int frames);
 
 /* Kernel choice for the same-resolution 3x3 layers of the per-frame path that have a Winograd F(4x4,3x3) pack (conv_f43_k):

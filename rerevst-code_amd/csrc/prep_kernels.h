@@ -75,9 +75,12 @@ __global__ void pack_last_k(const float* __restrict__ w, float* __restrict__ dst
 
 // ---- folds of a dynamic 32x32 filter F (weight[out=i][in=j] = F[i][j], quirk Q2) -----
 // down' = F . Wd :  Wd'[o][ci][t] = sum_m F[o][m] Wd[m][ci][t],  bd'[o] = sum_m F[o][m] bd[m]
+// blockIdx.y = state set (the grouped multi-style launches fold a group's sets at once): F, Wout, bout advance by
+// f_stride, 32 * CinT, b_stride floats per set
 __global__ void fold_down_k(const float* __restrict__ F, const float* __restrict__ Wd, const float* __restrict__ bd,
-                            float* __restrict__ Wout, float* __restrict__ bout, int CinT /* Cin*taps */) {
+                            float* __restrict__ Wout, float* __restrict__ bout, int CinT /* Cin*taps */, int f_stride, int b_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 32*CinT
+    F += (size_t)blockIdx.y * f_stride; Wout += (size_t)blockIdx.y * 32 * CinT; bout += (size_t)blockIdx.y * b_stride;
     if (i < 32 * CinT) {
         const int o = i / CinT, k = i - o * CinT;
         float s = 0.f;
@@ -91,8 +94,9 @@ __global__ void fold_down_k(const float* __restrict__ F, const float* __restrict
     }
 }
 // up' = Wu . F :  Wu'[o][j][t] = sum_m Wu[o][m][t] F[m][j]
-__global__ void fold_up_k(const float* __restrict__ F, const float* __restrict__ Wu, float* __restrict__ Wout, int Cout) {
+__global__ void fold_up_k(const float* __restrict__ F, const float* __restrict__ Wu, float* __restrict__ Wout, int Cout, int f_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over Cout*32*9
+    F += (size_t)blockIdx.y * f_stride; Wout += (size_t)blockIdx.y * Cout * 32 * 9;      // blockIdx.y = state set
     if (i < Cout * 32 * 9) {
         const int t = i % 9, j = (i / 9) & 31, o = i / (9 * 32);
         float s = 0.f;
@@ -513,7 +517,17 @@ __global__ void identity_norm_k(float* __restrict__ n, int C) {
 
 // blended state for multi-style interpolation: out = sum_s w[s] * state_s
 // ("Multi-style Interpolation/style_network.py":41-45,137-138,354-356)
+// (blend_states_k: blockIdx.y = image of a grouped multi-style launch, its weights w[image][style], its state set out + image * count)
+struct BlendManyP { const float* st[8]; float w[16][8]; int n; float* out; int count; };
 struct BlendP { const float* st[8]; float w[8]; int n; float* out; int count; };
+__global__ void blend_states_k(const BlendManyP p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i < p.count) {
+        float s = 0.f;
+        for (int k = 0; k < p.n; ++k) s += p.w[b][k] * p.st[k][i];      // the same sum, in the same order, as blend_state_k
+        p.out[(size_t)b * p.count + i] = s;
+    }
+}
 __global__ void blend_state_k(const BlendP p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < p.count) {

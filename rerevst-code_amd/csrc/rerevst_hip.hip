@@ -130,7 +130,8 @@ struct rrv_ctx {
     // since every frame there has its own blended state.  `cur` = the set the launch helpers use right now.
     // The sets live in CONTIGUOUS arrays (set i = base + i * stride): a launch whose images carry their own blended state
     // (rrv_transfer_features_batch) passes the first set and the strides, the kernels index by image.
-    static constexpr int N_SETS = 8;             // two groups of up to four multi-style frames in flight
+    static constexpr int MS_GROUP_MAX = 16;      // multi-style frames per launch sequence (each with its own blended state set)
+    static constexpr int N_SETS = 2 * MS_GROUP_MAX;      // two groups in flight (6.3 MB per set: state blob + folded KernelFilter weights)
     struct StateSet { float* active = nullptr; ConvW fold_down[3], fold_up[3]; } sets[N_SETS];
     StateSet* cur = &sets[0];
     int state_images = 0;                        // > 0: the launch's images 0..state_images-1 use sets cur, cur+1, .. (per-image state)
@@ -181,7 +182,7 @@ struct rrv_ctx {
     bool illcond = false;             // some computed style's state is ill-conditioned (StyleState::illcond)
     bool f43_path = false;            // true inside transfer_device only: the preparation pass (prepare_style / add / compute, frame mode) always runs F(2x2,3x3)
     unsigned direct_layers = 0;       // RRV_DIRECT_LAYERS: encoder convs (bit i = vgg conv i: 1 conv1_2 .. 8 conv4_1) of the per-frame path that run the direct-form kernel
-    int ms_group = 2;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch
+    int ms_group = 0;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch (0 = by the frame size)
     int host_io = 0;                  // rrv_set_host_io: 0 = staged H2D / D2H copies, 1 = zero copy (kernels read / write page-locked host memory), 2 = input only, 3 = output only
     // One-frame launches as hipGraphs (round 5): the 35 launches of a plain B = 1 transfer are captured once per (slot, geometry,
     // buffers, kernel choice) and replayed — same kernels, same arguments, same bits; the dispatch gaps between the kernels
@@ -709,7 +710,9 @@ int pointwise(rrv_handle h, const Tens& x, Tens& y, const float* mean, const flo
 // ---- folded KernelFilter weights for a state blob ------------------------------------------
 // (both folded layers run the row-split transform-domain kernel everywhere — per-frame path and compute()'s frame-0
 // residual alike — so only the Winograd packs are built)
-int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
+// nsets > 1: the state sets h->cur, h->cur + 1, .. (blobs RRV_STATE_FLOATS apart, folded weights set-major) in one launch each —
+// a set's packed 32-cout slabs follow the previous set's, so the pack is the pack of a layer with nsets x the couts.
+int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/, int nsets = 1) {
     char pre[64];
     snprintf(pre, sizeof pre, "Decoder.Filter%d", f + 1);
     const ConvW& wd = h->conv[std::string(pre) + ".down_sample.0"];
@@ -718,13 +721,20 @@ int fold_filters(rrv_handle h, const float* blob, int f /*0..2*/) {
     ConvW& fu = h->cur->fold_up[f];
     const float* F1 = blob + SL.filt[2 * f];
     const float* F2 = blob + SL.filt[2 * f + 1];
-    hipLaunchKernelGGL(fold_down_k, dim3((32 * 512 * 9 + 255) / 256), dim3(256), 0, h->stream, F1, (const float*)wd.raw,
-                       (const float*)wd.bias, fd.raw, fd.bias, 512 * 9);
+    hipLaunchKernelGGL(fold_down_k, dim3((32 * 512 * 9 + 255) / 256, nsets), dim3(256), 0, h->stream, F1, (const float*)wd.raw,
+                       (const float*)wd.bias, fd.raw, fd.bias, 512 * 9, (int)RRV_STATE_FLOATS, 256);
     HIPCHK(hipGetLastError());
-    RCHK(pack_wino(h, fd));          // 512->32 is one Winograd cout slab
-    hipLaunchKernelGGL(fold_up_k, dim3((512 * 32 * 9 + 255) / 256), dim3(256), 0, h->stream, F2, (const float*)wu.raw, fu.raw, 512);
+    hipLaunchKernelGGL(fold_up_k, dim3((512 * 32 * 9 + 255) / 256, nsets), dim3(256), 0, h->stream, F2, (const float*)wu.raw, fu.raw, 512, (int)RRV_STATE_FLOATS);
     HIPCHK(hipGetLastError());
-    RCHK(pack_wino(h, fu));          // 32 input channels = two 16-channel chunks per work item
+    if (nsets == 1) {
+        RCHK(pack_wino(h, fd));          // 512->32 is one Winograd cout slab
+        RCHK(pack_wino(h, fu));          // 32 input channels = two 16-channel chunks per work item
+    } else {
+        hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)fd.raw, fd.pk_wino, 32 * nsets, 512, 0);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(pack_wino_k, dim3(4096), dim3(256), 0, h->stream, (const float*)fu.raw, fu.pk_wino, 512 * nsets, 32, 0);
+        HIPCHK(hipGetLastError());
+    }
     return RRV_OK;
 }
 
@@ -2593,12 +2603,12 @@ int rrv_transfer_features(rrv_handle h, int feature_id, const float* wts, int ns
     return RRV_OK;
 }
 
-// n cached features, one weight vector each ([n][ns]), in ONE call.  Frames run in GROUPS of up to four per launch
+// n cached features, one weight vector each ([n][ns]), in ONE call.  Frames run in GROUPS of up to sixteen per launch
 // sequence — every image of a launch carries its own blended state set (per-image parameters and folded KernelFilter
 // weights, ConvP::par_bstride / w_bstride), so the small relu4_1-level layers see G x the pixel tiles of one frame —
-// and consecutive groups alternate over two (stream, workspace, four state sets): group k+1's blends, folds and
-// decoder overlap group k's D2H copy.  A frame's arithmetic does not depend on its group (bit-identical to one frame
-// per call).  Features beyond the cache cap (kept as pixels) run alone through the encoder + decoder entry.
+// and consecutive groups alternate over two (stream, workspace, sixteen state sets): group k+1's blends, folds and
+// decoder overlap group k's D2H copy.  With a fixed kernel mode a frame's arithmetic does not depend on its group
+// (bit-identical to one frame per call); the default mode chooses the kernels by the group's frames.  Features beyond the cache cap (kept as pixels) run alone through the encoder + decoder entry.
 int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, int n, int ns, float* out) {
     if (!h || !ids || !wts || !out || n < 1 || ns < 1 || ns > RRV_MAX_STYLES) return RRV_E_ARG;
     HIPCHK(hipSetDevice(h->dev));
@@ -2613,7 +2623,14 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
     RCHK(sync_all(h));
     const size_t npx = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
     const bool out_pin = is_pinned(out, (size_t)n * npx * sizeof(float));
-    int G = h->ms_group;       // rrv_set_multistyle_group (default 2: 371 / 382 / 381 frames/s for 1 / 2 / 4 at 1152 x 1152 x 4 styles, conv_f43_k with per-image parameters)
+    // Frames per launch sequence (rrv_set_multistyle_group; default: the host entries' ~6.6 Mpixel per launch — 4 at 1152 x 1152,
+    // 16 at 640 x 640 and below).  Measured with four styles (conv_f43_k with per-image parameters, round 5): 1152 x 1152
+    // 371 / 382 / 381 frames/s for 1 / 2 / 4; 640 x 640 941 / 1070 / 1167; 384 x 384 1750 / 2163 / 2590.
+    int G = h->ms_group;
+    if (G == 0) {
+        const long s = HOST_SUB_PIXELS / ((long)H * W);
+        G = s < 1 ? 1 : s > rrv_ctx::MS_GROUP_MAX ? rrv_ctx::MS_GROUP_MAX : (int)s;
+    }
     if (G > n) G = n;
     struct Group { int first, count; };
     std::vector<Group> groups;
@@ -2660,18 +2677,21 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
             HIPCHK(hipStreamWaitEvent(h->streams[slot], st.out_done, 0));      // this slot's device output has left
         }
         h->stream = h->streams[slot];
-        const float* fp[4] = {nullptr, nullptr, nullptr, nullptr};
-        for (int g = 0; g < cnt; ++g) {      // image g of the group: state set 4 * slot + g
-            h->cur = &h->sets[4 * slot + g];
-            BlendP bp{};
+        const float* fp[rrv_ctx::MS_GROUP_MAX] = {};
+        h->cur = &h->sets[rrv_ctx::MS_GROUP_MAX * slot];       // image g of the group: state set MS_GROUP_MAX * slot + g
+        {   // the group's blends and folds: one launch per step for all its images (same sums as the one-image kernels)
+            static_assert(rrv_ctx::MS_GROUP_MAX <= 16, "BlendManyP::w holds sixteen images");
+            BlendManyP bp{};
             bp.n = ns; bp.out = h->cur->active; bp.count = RRV_STATE_FLOATS;
-            for (int s = 0; s < ns; ++s) { bp.st[s] = h->styles[s].blob; bp.w[s] = wts[(size_t)(first + g) * ns + s]; }
-            hipLaunchKernelGGL(blend_state_k, dim3((RRV_STATE_FLOATS + 255) / 256), dim3(256), 0, h->stream, bp);
+            for (int s = 0; s < ns; ++s) bp.st[s] = h->styles[s].blob;
+            for (int g = 0; g < cnt; ++g) {
+                for (int s = 0; s < ns; ++s) bp.w[g][s] = wts[(size_t)(first + g) * ns + s];
+                fp[g] = h->features[ids[first + g]].p;
+            }
+            hipLaunchKernelGGL(blend_states_k, dim3((RRV_STATE_FLOATS + 255) / 256, cnt), dim3(256), 0, h->stream, bp);
             HIPCHK(hipGetLastError());
-            for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f));
-            fp[g] = h->features[ids[first + g]].p;
+            for (int f = 0; f < 3; ++f) RCHK(fold_filters(h, h->cur->active, f, cnt));
         }
-        h->cur = &h->sets[4 * slot];
         h->active_src = -2;
         h->next_slot = slot;
         if (fp[0] && cnt == 1) {       // one frame per launch: its state set is simply the current one (shared-state kernels)
@@ -2769,7 +2789,7 @@ int rrv_set_f43(rrv_handle h, int mode) {
 }
 
 int rrv_set_multistyle_group(rrv_handle h, int frames) {
-    if (!h || frames < 1 || frames > 4) return RRV_E_ARG;
+    if (!h || frames < 0 || frames > rrv_ctx::MS_GROUP_MAX) return RRV_E_ARG;
     h->ms_group = frames;
     return RRV_OK;
 }

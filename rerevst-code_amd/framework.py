@@ -463,7 +463,7 @@ class MultiStyleStylization(Stylization):
         self._chk(self._lib.rrv_release_features(self._h))
 
     def set_multistyle_group(self, frames):
-        """Frames per launch sequence of transfer_many (1..4): per-image blended state inside one launch."""
+        """Frames per launch sequence of transfer_many (1..16; 0 = by the frame size, the default): per-image blended state inside one launch."""
         self._chk(self._lib.rrv_set_multistyle_group(self._h, int(frames)))
 
     def set_feature_cache_cap(self, nbytes):

@@ -122,11 +122,11 @@ def test_real_multistyle_matches_reference(pkg, weights, oracle):
     assert np.abs(out[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
     assert np.abs(out[186:250, 480:544] - g["out_patch"]).max() <= IMG_ATOL
     np.testing.assert_allclose(out.mean(axis=(0, 1)), g["out_chanmean"], atol=2e-3)
-    many = s.transfer_many([feats[tid], feats[0]], [wts, [0.0, 1.0]])                 # the driver's frame loop in one call (two frames per launch)
+    many = s.transfer_many([feats[tid], feats[0]], [wts, [0.0, 1.0]])                 # the driver's frame loop in one call (both frames in one launch)
     assert np.abs(many[0][64:500, 64:1088][::4, ::4] - g["out_grid"]).max() <= IMG_ATOL
     s.set_multistyle_group(1)                                                         # one frame per launch: the one-frame entry's bits
     np.testing.assert_array_equal(s.transfer_many([feats[tid], feats[0]], [wts, [0.0, 1.0]])[0][64:500, 64:1088], out)
-    s.set_multistyle_group(2)
+    s.set_multistyle_group(0)
     full = pkg.Stylization.transfer(s, padded[tid], style_weight=wts)[64:500, 64:1088]      # encoder + blended decoder from the frame
     assert np.abs(full[::4, ::4] - g["out_grid"]).max() <= IMG_ATOL                        # (its encoder may run F(4x4,3x3); the cached features never do)
     with fixed_kernels(s):                 # one kernel family for the encoder of both entries: the same numbers to 1e-3
