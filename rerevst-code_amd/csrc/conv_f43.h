@@ -42,51 +42,9 @@
 #ifndef F43_ABL
 #define F43_ABL 0
 #endif
-// F43_DMA: where a wave issues the 19 LDS-DMA requests of a chunk (tools/f43_bench.hip builds one binary per value;
-// profiles/r05_f43_timeline.txt): 0 all in the mini gap of run `wave` | 1 one per position step from step 0, all waves together |
-// 2 two per step, wave w in steps 5w..5w+9 | 3 one per step, wave w from step 4w | 4 inside the input transform that precedes the
-// chunk | 5 one burst right behind the chunk barrier (4 and 5: a VALU-only phase prices a request lower, but both compile with
-// VGPR spills and run 30 % slower) | 6 / 7 / 8 one request every 28/19, 36/19, 24/19 position steps (the CU's L2 -> LDS path
-// sustains 13-20 B/clock, the kernel needs 76 KB per ~7 000-clock chunk: requests issued faster than that stall the issuing wave).
-// The library ships 6 (+3.5-4.5 % over 1, +6-8 % over round 4's 0).
-#ifndef F43_DMA
-#define F43_DMA 6
-#endif
-// F43_TAIL: 0 barrier, first U batch, whole input transform | 1 column passes of the transform BEFORE the barrier (they need
-// nothing the barrier guards and absorb the waves' skew), row passes behind the first U batch's reads
-#ifndef F43_TAIL
-#define F43_TAIL 0
-#endif
-// F43_RD2: 1 = the patch pieces (dy, dx), (dy + 1, dx) by ONE ds_read2_b64 (18 LDS instructions per chunk instead of 36;
-// six base-address registers instead of two: the offsets of ds_read2 are 8-bit, in units of 8 bytes)
-#ifndef F43_RD2
-#define F43_RD2 0
-#endif
-// F43_KS: 1 = the six multipliers of the input transform are loaded into SGPR pairs ONCE per transform (6 s_mov_b64 instead
-// of 24, no SALU -> VALU wait states inside the op stream; tools/pkfma_bench.hip: 5.1 instead of 5.8 clocks per packed op)
-#ifndef F43_KS
-#define F43_KS 1
-#endif
-// F43_AS: 1 = the ten halo address registers of the LDS-DMA live in AGPRs (written once per launch, read into a scratch VGPR
-// right before each request): ten VGPRs less pressure in the phases that issue requests
-#ifndef F43_AS
-#define F43_AS 0
-#endif
-// F43_UMID: 1 = the next chunk's first U batch is read BETWEEN the column and the row passes of the input transform (not before
-// it): its 24 registers are not live while the column passes run — where F43_DMA == 4 issues its requests — and the row
-// passes (72 packed ops) still cover the LDS latency
-#ifndef F43_UMID
-#define F43_UMID 0
-#endif
-// F43_U1: 1 = the U fragments come one position step at a time through a ring of four (read three steps ahead, counted
-// lgkmcnt per step) instead of six per MFMA run through two batches of six: 16 registers instead of 48
-#ifndef F43_U1
-#define F43_U1 0
-#endif
-// F43_L3: 1 = three lines of the input transform in lockstep instead of six (needs F43_KS; 48 op groups of three)
-#ifndef F43_L3
-#define F43_L3 1
-#endif
+// Measured-and-lost variants of this kernel (where the LDS-DMA requests go: F43_DMA 0-5, 7, 8; F43_TAIL, F43_RD2, F43_AS, F43_UMID,
+// F43_U1; six transform lines in lockstep) are in the git history up to 0a3fa2e and in profiles/r05_f43_timeline.txt; what
+// ships: one request every 28/19 position steps, the six transform multipliers in SGPR pairs, three lines in lockstep.
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -103,19 +61,9 @@ struct F43Geo {
 };
 
 // ---- packed fp32 helpers (v_pk_* through inline asm: the compiler has no packed form for constants / subtractions)
-__device__ __forceinline__ f32x2 p2add(const f32x2 a, const f32x2 b) {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 __device__ __forceinline__ f32x2 p2sub(const f32x2 a, const f32x2 b) {
     f32x2 r;
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ f32x2 p2fma(const f32x2 a, const f32x2 k, const f32x2 c) {      // a * k + c
-    f32x2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(k), "v"(c));
     return r;
 }
 template <int IMM>
@@ -162,87 +110,13 @@ constexpr float F43_A2 = F43_A * F43_A, F43_B2 = F43_B * F43_B, F43_P = F43_A2 *
 constexpr float F43_A3 = F43_A2 * F43_A, F43_B3 = F43_B2 * F43_B;
 constexpr unsigned f43_bits(float f) { return __builtin_bit_cast(unsigned, f); }
 
-// r = x * (+-K) + c on a channel pair, K = the float with bit pattern KB
-template <unsigned KB, bool NEG>
-__device__ __forceinline__ f32x2 t2fmak(const f32x2 x, const f32x2 c) {
-    f32x2 r;
-    unsigned long long ks;
-    if constexpr (NEG) asm volatile("s_mov_b64 %1, %4\n\tv_pk_fma_f32 %0, %2, %1, %3 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r), "=&s"(ks) : "v"(x), "v"(c), "i"(KB));
-    else asm volatile("s_mov_b64 %1, %4\n\tv_pk_fma_f32 %0, %2, %1, %3 op_sel_hi:[1,0,1]" : "=v"(r), "=&s"(ks) : "v"(x), "v"(c), "i"(KB));
-    return r;
-}
-template <unsigned KB>
-__device__ __forceinline__ f32x2 t2mulk(const f32x2 x) {      // x * K
-    f32x2 r;
-    unsigned long long ks;
-    asm volatile("s_mov_b64 %1, %3\n\tv_pk_mul_f32 %0, %2, %1 op_sel_hi:[1,0]" : "=v"(r), "=&s"(ks) : "v"(x), "i"(KB));
-    return r;
-}
-template <int PK>
-__device__ __forceinline__ f32x2 t2add(const f32x2 x, const f32x2 y) {
-    f32x2 r;
-    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-template <int PK>
-__device__ __forceinline__ f32x2 t2sub(const f32x2 x, const f32x2 y) {
-    f32x2 r;
-    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-// SIX independent lines, one op of the 1-D input transform each, in ONE asm statement: r[n] = x[n] * (+-K) + c[n].  The six
-// packed FMAs share one constant load, and the five instructions behind an op never need its result (a dependent packed
-// op would wait ~9 cycles, an independent one issues in ~4).  Outputs are early-clobber: they are written while later
-// lines' inputs are still to be read.
-template <unsigned KB, bool NEG>
-__device__ __forceinline__ void fmak6(f32x2& r0, f32x2& r1, f32x2& r2, f32x2& r3, f32x2& r4, f32x2& r5,
-                                      const f32x2 x0, const f32x2 x1, const f32x2 x2, const f32x2 x3, const f32x2 x4, const f32x2 x5,
-                                      const f32x2 c0, const f32x2 c1, const f32x2 c2, const f32x2 c3, const f32x2 c4, const f32x2 c5) {
-    unsigned long long ks;
-#define F43_L(N, X, C) "v_pk_fma_f32 %" #N ", %" #X ", %6, %" #C " op_sel_hi:[1,0,1]"
-#define F43_LN(N, X, C) F43_L(N, X, C) " neg_lo:[0,1,0] neg_hi:[0,1,0]"
-    if constexpr (NEG)
-        asm volatile("s_mov_b64 %6, %19\n\t" F43_LN(0, 7, 13) "\n\t" F43_LN(1, 8, 14) "\n\t" F43_LN(2, 9, 15) "\n\t" F43_LN(3, 10, 16) "\n\t" F43_LN(4, 11, 17) "\n\t" F43_LN(5, 12, 18)
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&s"(ks)
-                     : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "i"(KB));
-    else
-        asm volatile("s_mov_b64 %6, %19\n\t" F43_L(0, 7, 13) "\n\t" F43_L(1, 8, 14) "\n\t" F43_L(2, 9, 15) "\n\t" F43_L(3, 10, 16) "\n\t" F43_L(4, 11, 17) "\n\t" F43_L(5, 12, 18)
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&s"(ks)
-                     : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "i"(KB));
-#undef F43_L
-#undef F43_LN
-}
-// The 1-D input transform B^T (6 -> 6) of SIX lines (all columns, or all rows, of a patch) as twelve ops in lockstep:
+// The 1-D input transform B^T (6 -> 6) of a line d0..d5 as twelve ops:
 //   0: A = d4 - B2 d2     1: B = d3 - B2 d1     2: C = d4 - A2 d2     3: F = d3 - A2 d1
 //   4: g = P d0 + d4      5: d0 = g - S d2      6: g = P d1 + d5      7: d5 = g - S d3
 //   8: d1 = A + a B       9: d2 = A - a B      10: d3 = C + b F      11: d4 = C - b F
-// L(n, j) = element j of line n.
+// with the six multipliers in SGPR pairs loaded ONCE per transform (no SALU -> VALU wait states inside the op stream;
+// tools/pkfma_bench.hip: 5.1 instead of 5.8 clocks per packed op): k = {B2, A2, P, S, A, B}.
 struct F43Tmp { f32x2 a, b, c, f, g; };
-struct F43NoHook { template <class I> __device__ __forceinline__ void operator()(I) const {} };
-// `hook(integral_constant<g>)` runs after op group g (0..11): conv_f43_k issues its LDS-DMA requests there (F43_DMA == 4)
-template <int PK, class LineFn, class Hook = F43NoHook>
-__device__ __forceinline__ void f43_in6(LineFn&& L, Hook&& hook = Hook{}) {
-    F43Tmp t[6];
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-#define F43_D(J) L(I0{}, I##J{}), L(I1{}, I##J{}), L(I2{}, I##J{}), L(I3{}, I##J{}), L(I4{}, I##J{}), L(I5{}, I##J{})
-#define F43_T(M) t[0].M, t[1].M, t[2].M, t[3].M, t[4].M, t[5].M
-    fmak6<f43_bits(F43_B2), true>(F43_T(a), F43_D(2), F43_D(4)); hook(std::integral_constant<int, 0>{});
-    fmak6<f43_bits(F43_B2), true>(F43_T(b), F43_D(1), F43_D(3)); hook(std::integral_constant<int, 1>{});
-    fmak6<f43_bits(F43_A2), true>(F43_T(c), F43_D(2), F43_D(4)); hook(std::integral_constant<int, 2>{});
-    fmak6<f43_bits(F43_A2), true>(F43_T(f), F43_D(1), F43_D(3)); hook(std::integral_constant<int, 3>{});
-    fmak6<f43_bits(F43_P), false>(F43_T(g), F43_D(0), F43_D(4)); hook(std::integral_constant<int, 4>{});
-    fmak6<f43_bits(F43_S), true>(F43_D(0), F43_D(2), F43_T(g)); hook(std::integral_constant<int, 5>{});
-    fmak6<f43_bits(F43_P), false>(F43_T(g), F43_D(1), F43_D(5)); hook(std::integral_constant<int, 6>{});
-    fmak6<f43_bits(F43_S), true>(F43_D(5), F43_D(3), F43_T(g)); hook(std::integral_constant<int, 7>{});
-    fmak6<f43_bits(F43_A), false>(F43_D(1), F43_T(b), F43_T(a)); hook(std::integral_constant<int, 8>{});
-    fmak6<f43_bits(F43_A), true>(F43_D(2), F43_T(b), F43_T(a)); hook(std::integral_constant<int, 9>{});
-    fmak6<f43_bits(F43_B), false>(F43_D(3), F43_T(f), F43_T(c)); hook(std::integral_constant<int, 10>{});
-    fmak6<f43_bits(F43_B), true>(F43_D(4), F43_T(f), F43_T(c)); hook(std::integral_constant<int, 11>{});
-#undef F43_D
-#undef F43_T
-}
-// The same with the multipliers already in SGPR pairs (F43_KS): k = {B2, A2, P, S, A, B}
 struct F43K { unsigned long long b2, a2, p, s, a, b; };
 __device__ __forceinline__ F43K f43_load_k() {
     F43K k;
@@ -251,48 +125,8 @@ __device__ __forceinline__ F43K f43_load_k() {
                  : "i"(f43_bits(F43_B2)), "i"(f43_bits(F43_A2)), "i"(f43_bits(F43_P)), "i"(f43_bits(F43_S)), "i"(f43_bits(F43_A)), "i"(f43_bits(F43_B)));
     return k;
 }
-template <bool NEG>
-__device__ __forceinline__ void fmak6s(f32x2& r0, f32x2& r1, f32x2& r2, f32x2& r3, f32x2& r4, f32x2& r5,
-                                       const f32x2 x0, const f32x2 x1, const f32x2 x2, const f32x2 x3, const f32x2 x4, const f32x2 x5,
-                                       const f32x2 c0, const f32x2 c1, const f32x2 c2, const f32x2 c3, const f32x2 c4, const f32x2 c5, const unsigned long long ks) {
-#define F43_L(N, X, C) "v_pk_fma_f32 %" #N ", %" #X ", %6, %" #C " op_sel_hi:[1,0,1]"
-#define F43_LN(N, X, C) F43_L(N, X, C) " neg_lo:[0,1,0] neg_hi:[0,1,0]"
-    if constexpr (NEG)
-        asm volatile(F43_LN(0, 7, 13) "\n\t" F43_LN(1, 8, 14) "\n\t" F43_LN(2, 9, 15) "\n\t" F43_LN(3, 10, 16) "\n\t" F43_LN(4, 11, 17) "\n\t" F43_LN(5, 12, 18)
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
-                     : "s"(ks), "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5));
-    else
-        asm volatile(F43_L(0, 7, 13) "\n\t" F43_L(1, 8, 14) "\n\t" F43_L(2, 9, 15) "\n\t" F43_L(3, 10, 16) "\n\t" F43_L(4, 11, 17) "\n\t" F43_L(5, 12, 18)
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
-                     : "s"(ks), "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5));
-#undef F43_L
-#undef F43_LN
-}
-template <class LineFn, class Hook = F43NoHook>
-__device__ __forceinline__ void f43_in6s(LineFn&& L, const F43K& k, Hook&& hook = Hook{}) {
-    F43Tmp t[6];
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-#define F43_D(J) L(I0{}, I##J{}), L(I1{}, I##J{}), L(I2{}, I##J{}), L(I3{}, I##J{}), L(I4{}, I##J{}), L(I5{}, I##J{})
-#define F43_T(M) t[0].M, t[1].M, t[2].M, t[3].M, t[4].M, t[5].M
-    fmak6s<true>(F43_T(a), F43_D(2), F43_D(4), k.b2); hook(std::integral_constant<int, 0>{});
-    fmak6s<true>(F43_T(b), F43_D(1), F43_D(3), k.b2); hook(std::integral_constant<int, 1>{});
-    fmak6s<true>(F43_T(c), F43_D(2), F43_D(4), k.a2); hook(std::integral_constant<int, 2>{});
-    fmak6s<true>(F43_T(f), F43_D(1), F43_D(3), k.a2); hook(std::integral_constant<int, 3>{});
-    fmak6s<false>(F43_T(g), F43_D(0), F43_D(4), k.p); hook(std::integral_constant<int, 4>{});
-    fmak6s<true>(F43_D(0), F43_D(2), F43_T(g), k.s); hook(std::integral_constant<int, 5>{});
-    fmak6s<false>(F43_T(g), F43_D(1), F43_D(5), k.p); hook(std::integral_constant<int, 6>{});
-    fmak6s<true>(F43_D(5), F43_D(3), F43_T(g), k.s); hook(std::integral_constant<int, 7>{});
-    fmak6s<false>(F43_D(1), F43_T(b), F43_T(a), k.a); hook(std::integral_constant<int, 8>{});
-    fmak6s<true>(F43_D(2), F43_T(b), F43_T(a), k.a); hook(std::integral_constant<int, 9>{});
-    fmak6s<false>(F43_D(3), F43_T(f), F43_T(c), k.b); hook(std::integral_constant<int, 10>{});
-    fmak6s<true>(F43_D(4), F43_T(f), F43_T(c), k.b); hook(std::integral_constant<int, 11>{});
-#undef F43_D
-#undef F43_T
-}
-// THREE lines in lockstep (F43_L3): an op's result is needed three ops (~15 clocks) later — still beyond the ~9 clocks a
-// dependent packed op waits — and the temporaries of a call are 30 registers instead of 60, which is what lets the ten
-// LDS-DMA address registers stay live through the transform (F43_DMA == 4) without spills.  LB = first line of the call.
+// THREE lines in lockstep: an op's result is needed three ops (~15 clocks) later — still beyond the ~9 clocks a dependent
+// packed op waits — and the temporaries of a call are 30 registers (six lines in lockstep: 60).  LB = first line of the call.
 template <bool NEG>
 __device__ __forceinline__ void fmak3s(f32x2& r0, f32x2& r1, f32x2& r2, const f32x2 x0, const f32x2 x1, const f32x2 x2,
                                        const f32x2 c0, const f32x2 c1, const f32x2 c2, const unsigned long long ks) {
@@ -304,26 +138,26 @@ __device__ __forceinline__ void fmak3s(f32x2& r0, f32x2& r1, f32x2& r2, const f3
         asm volatile("v_pk_fma_f32 %0, %4, %3, %7 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %5, %3, %8 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %2, %6, %3, %9 op_sel_hi:[1,0,1]"
                      : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "s"(ks), "v"(x0), "v"(x1), "v"(x2), "v"(c0), "v"(c1), "v"(c2));
 }
-template <int LB, class LineFn, class Hook = F43NoHook>
-__device__ __forceinline__ void f43_in3s(LineFn&& L, const F43K& k, Hook&& hook = Hook{}) {
+template <int LB, class LineFn>
+__device__ __forceinline__ void f43_in3s(LineFn&& L, const F43K& k) {
     F43Tmp t[3];
     using N0 = std::integral_constant<int, LB>; using N1 = std::integral_constant<int, LB + 1>; using N2 = std::integral_constant<int, LB + 2>;
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
 #define F43_D(J) L(N0{}, I##J{}), L(N1{}, I##J{}), L(N2{}, I##J{})
 #define F43_T(M) t[0].M, t[1].M, t[2].M
-    fmak3s<true>(F43_T(a), F43_D(2), F43_D(4), k.b2); hook(std::integral_constant<int, 0>{});
-    fmak3s<true>(F43_T(b), F43_D(1), F43_D(3), k.b2); hook(std::integral_constant<int, 1>{});
-    fmak3s<true>(F43_T(c), F43_D(2), F43_D(4), k.a2); hook(std::integral_constant<int, 2>{});
-    fmak3s<true>(F43_T(f), F43_D(1), F43_D(3), k.a2); hook(std::integral_constant<int, 3>{});
-    fmak3s<false>(F43_T(g), F43_D(0), F43_D(4), k.p); hook(std::integral_constant<int, 4>{});
-    fmak3s<true>(F43_D(0), F43_D(2), F43_T(g), k.s); hook(std::integral_constant<int, 5>{});
-    fmak3s<false>(F43_T(g), F43_D(1), F43_D(5), k.p); hook(std::integral_constant<int, 6>{});
-    fmak3s<true>(F43_D(5), F43_D(3), F43_T(g), k.s); hook(std::integral_constant<int, 7>{});
-    fmak3s<false>(F43_D(1), F43_T(b), F43_T(a), k.a); hook(std::integral_constant<int, 8>{});
-    fmak3s<true>(F43_D(2), F43_T(b), F43_T(a), k.a); hook(std::integral_constant<int, 9>{});
-    fmak3s<false>(F43_D(3), F43_T(f), F43_T(c), k.b); hook(std::integral_constant<int, 10>{});
-    fmak3s<true>(F43_D(4), F43_T(f), F43_T(c), k.b); hook(std::integral_constant<int, 11>{});
+    fmak3s<true>(F43_T(a), F43_D(2), F43_D(4), k.b2);
+    fmak3s<true>(F43_T(b), F43_D(1), F43_D(3), k.b2);
+    fmak3s<true>(F43_T(c), F43_D(2), F43_D(4), k.a2);
+    fmak3s<true>(F43_T(f), F43_D(1), F43_D(3), k.a2);
+    fmak3s<false>(F43_T(g), F43_D(0), F43_D(4), k.p);
+    fmak3s<true>(F43_D(0), F43_D(2), F43_T(g), k.s);
+    fmak3s<false>(F43_T(g), F43_D(1), F43_D(5), k.p);
+    fmak3s<true>(F43_D(5), F43_D(3), F43_T(g), k.s);
+    fmak3s<false>(F43_D(1), F43_T(b), F43_T(a), k.a);
+    fmak3s<true>(F43_D(2), F43_T(b), F43_T(a), k.a);
+    fmak3s<false>(F43_D(3), F43_T(f), F43_T(c), k.b);
+    fmak3s<true>(F43_D(4), F43_T(f), F43_T(c), k.b);
 #undef F43_D
 #undef F43_T
 }
@@ -364,7 +198,6 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     static_assert(!(EPI & E_RES), "same-resolution residuals are not needed by the layers this kernel serves");
     using G = F43Geo;
     constexpr int ABL = F43_ABL;      // microbenchmark switches; 0 in the library
-    constexpr int PK = 1;             // packed-fp32 input transform (one v_pk_* per op; measured 4-7 % faster than scalar pairs)
     constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, NT = G::NT, NPOS = G::NPOS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -423,17 +256,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         const int half = e & 1, xd = (e >> 1) % 9, ph = ((e >> 1) / 9) & 3, y = (e >> 1) / 36;
         const int x = 4 * xd + ph, par = (y >> 2) & 1;
         asrc[it] = ((y * (p.Wi + 2) + x) * p.Cin + 4 * (half ^ par)) * 4;
-        if constexpr (F43_AS == 1) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(asrc[it]) : "v"(asrc[it]));
     }
-    auto asrc_of = [&](int it) {
-        if constexpr (F43_AS == 1) {
-            int t;
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(asrc[it]));
-            return t;
-        } else {
-            return asrc[it];
-        }
-    };
     bool have = cur.b < p.B, have_nxt = false;
     const float* in_t = in_of(cur);
     const float* w_t = w_of(cur);
@@ -450,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         char* rdst = smem + (chunk & 1) * RAW_BYTES;
         const rsrc_t rs = make_rsrc(in_t, lim_t);
 #pragma unroll
-        for (int it = 0; it < G::RAW_IT; ++it) bufld16_rs(rs, rdst + (it * NT + wave * 64) * 16, asrc_of(it), chunk * 32);
+        for (int it = 0; it < G::RAW_IT; ++it) bufld16_rs(rs, rdst + (it * NT + wave * 64) * 16, asrc[it], chunk * 32);
     };
     char* const par = smem + 2 * RAW_BYTES + 2 * U_BYTES;
     // img: the item's image.  Per-image state (ConvP::par_bstride != 0, the grouped multi-style decoder): image b reads its
@@ -492,113 +315,24 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     auto tick = [&](int k) { if (ABL & 16) { const long long n = clock64(); tl[k] += n - tl_t; tl_t = n; } };
     f32x2 v[NPOS];                // transformed patch B^T d B of the chunk in flight: V[r][k] at index k*6 + r (raw piece (dy, dx) at dx*6 + dy)
     f32x4 ur[2][6];               // U fragments of two position batches: [ring slot][r] = {block 0: channels 2q, 2q+1; block 1: the same}
-    f32x4 u1[4];                  // F43_U1: ring of four position steps (step s = b*6 + r in slot s & 3)
-    auto read_u1 = [&](unsigned ub, auto sc) {      // U fragments of position step s (position r*6 + b) -> u1[s & 3]
-        constexpr int st = decltype(sc)::value, pos = (st % 6) * 6 + st / 6;
-        u1[st & 3] = lds_rd128<pos * 1024>(ub);
-    };
-    auto read_u1_first = [&](unsigned ub) {          // steps 0, 1, 2 of a chunk (behind the barrier that publishes its U block)
-        read_u1(ub, std::integral_constant<int, 0>{}); read_u1(ub, std::integral_constant<int, 1>{}); read_u1(ub, std::integral_constant<int, 2>{});
-    };
-    // `hook(integral_constant<g>)` runs after op group g = 0..23 of the 24 (F43_DMA == 4: one LDS-DMA request each)
-    auto full_transform = [&](f32x2 (&d)[NPOS], auto&& hook, auto&& mid) {
-        // column passes: line dx = d[6 dx + 0..5]; then row passes: line r = d[r], d[6 + r], .., d[30 + r]
-        auto h0 = [&](auto gc) { hook(std::integral_constant<int, decltype(gc)::value>{}); };
-        auto h1 = [&](auto gc) { hook(std::integral_constant<int, 12 + decltype(gc)::value>{}); };
-        if constexpr (F43_KS == 1 && F43_L3 == 1) {      // 48 groups of three ops: the hook sees every second one
-            const F43K k = f43_load_k();
-            auto col = [&](auto nc, auto jc) -> f32x2& { return d[decltype(nc)::value * 6 + decltype(jc)::value]; };
-            auto row = [&](auto nc, auto jc) -> f32x2& { return d[decltype(jc)::value * 6 + decltype(nc)::value]; };
-            auto hk = [&](auto basec) { return [&](auto gc) {
-                constexpr int g = decltype(basec)::value + decltype(gc)::value;
-                if constexpr (F43_UMID == 1) hook(std::integral_constant<int, g>{});                 // one request after each of the first 19 groups: all inside the column passes
-                else if constexpr ((g & 1) == 0) hook(std::integral_constant<int, g / 2>{});
-            }; };
-            f43_in3s<0>(col, k, hk(std::integral_constant<int, 0>{}));
-            f43_in3s<3>(col, k, hk(std::integral_constant<int, 12>{}));
-            mid();
-            f43_in3s<0>(row, k, hk(std::integral_constant<int, 24>{}));
-            f43_in3s<3>(row, k, hk(std::integral_constant<int, 36>{}));
-        } else if constexpr (F43_KS == 1) {
-            const F43K k = f43_load_k();
-            f43_in6s([&](auto nc, auto jc) -> f32x2& { return d[decltype(nc)::value * 6 + decltype(jc)::value]; }, k, h0);
-            mid();
-            f43_in6s([&](auto nc, auto jc) -> f32x2& { return d[decltype(jc)::value * 6 + decltype(nc)::value]; }, k, h1);
-        } else {
-            f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return d[decltype(nc)::value * 6 + decltype(jc)::value]; }, h0);
-            mid();
-            f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return d[decltype(jc)::value * 6 + decltype(nc)::value]; }, h1);
-        }
-    };
-    // F43_DMA == 4: the 19 LDS-DMA requests that chunk `cn` needs issued (U(cn+1) -> U buffer (cn+1)&1, halo(cn+2) -> raw buffer
-    // cn&1; past the item's end the next item's U(0), halo(0), halo(1)) go out inside the input transform that PRECEDES chunk
-    // cn — a VALU-only phase, where a request costs 25-60 clocks of issue instead of 60-185 between MFMAs and LDS reads
-    // (MI355X_MICROARCH.md) — one after each of the first 19 op groups.  Both buffers are free there: the transform runs
-    // behind the barrier that ends chunk cn-1 (or behind next_patch's barrier at an item's start).
-    auto dma_hook5 = [&](int cn) {
-        const bool own_u = cn + 1 < nchunks, own_r = cn + 2 < nchunks;
-        const rsrc_t rs_u = make_rsrc(own_u ? w_t : w_n);
-        const rsrc_t rs_r = make_rsrc(own_r ? in_t : in_n, own_r ? lim_t : lim_n);
-        const int usoff = own_u ? (cn + 1) * U_BYTES : 0;
-        const int rsoff = (own_r ? cn + 2 : cn + 2 - nchunks) * 32;
-        char* const udst = smem + 2 * RAW_BYTES + (1 - (cn & 1)) * U_BYTES;
-        char* const rdst = smem + (cn & 1) * RAW_BYTES;
-        return [=](auto gc) {
-            constexpr int n = decltype(gc)::value;
-            if (!(ABL & 1)) {
-                if constexpr (n < G::RAW_IT) bufld16_rs(rs_r, rdst + (n * NT + wave * 64) * 16, asrc_of(n), rsoff);
-                else bufld16_rs(rs_u, udst + ((n - G::RAW_IT) * NT + wave * 64) * 16, tid * 16, usoff + (n - G::RAW_IT) * NT * 16);
-            }
-        };
-    };
-    auto dma_hook = [&](int cn, bool enable) {
-        const bool own_u = cn + 1 < nchunks, own_r = cn + 2 < nchunks;
-        const rsrc_t rs_u = make_rsrc(own_u ? w_t : w_n);
-        const rsrc_t rs_r = make_rsrc(own_r ? in_t : in_n, own_r ? lim_t : lim_n);
-        const int usoff = own_u ? (cn + 1) * U_BYTES : 0;
-        const int rsoff = (own_r ? cn + 2 : cn + 2 - nchunks) * 32;
-        char* const udst = smem + 2 * RAW_BYTES + (1 - (cn & 1)) * U_BYTES;
-        char* const rdst = smem + (cn & 1) * RAW_BYTES;
-        return [=](auto gc) {
-            constexpr int n = decltype(gc)::value;
-            if constexpr (F43_DMA == 4 && n < G::RAW_IT + G::U_IT) {
-                if (enable && !(ABL & 1)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (n < G::RAW_IT) bufld16_rs(rs_r, rdst + (n * NT + wave * 64) * 16, asrc_of(n), rsoff);
-                    else bufld16_rs(rs_u, udst + ((n - G::RAW_IT) * NT + wave * 64) * 16, tid * 16, usoff + (n - G::RAW_IT) * NT * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
+    // the 2-D input transform of the patch in d: column passes (line dx = d[6 dx + 0..5]), then row passes (line r = d[r], d[6 + r], .., d[30 + r])
+    auto full_transform = [&](f32x2 (&d)[NPOS]) {
+        const F43K k = f43_load_k();
+        auto col = [&](auto nc, auto jc) -> f32x2& { return d[decltype(nc)::value * 6 + decltype(jc)::value]; };
+        auto row = [&](auto nc, auto jc) -> f32x2& { return d[decltype(jc)::value * 6 + decltype(nc)::value]; };
+        f43_in3s<0>(col, k);
+        f43_in3s<3>(col, k);
+        f43_in3s<0>(row, k);
+        f43_in3s<3>(row, k);
     };
     // patch piece (dy, dx) of the raw tile in raw buffer `RB` (byte offset) -> v[dx*6 + dy]
-    // F43_RD2: base addresses of the row pairs (0,1), (2,3), (4,5) in both raw buffers
-    unsigned raw2[2][3];
-    if constexpr (F43_RD2 == 1) {
-#pragma unroll
-        for (int bf = 0; bf < 2; ++bf) {
-            raw2[bf][0] = rawA + bf * RAW_BYTES; raw2[bf][1] = rawA + bf * RAW_BYTES + 2 * G::RAW_ROW_BYTES; raw2[bf][2] = rawB + bf * RAW_BYTES + 4 * G::RAW_ROW_BYTES;
-        }
-    }
     auto read_patch_col = [&](auto rbc, auto dxc) {
         constexpr int RB = decltype(rbc)::value, dx = decltype(dxc)::value;
-        if constexpr (F43_RD2 == 1) {
-            static_for([&](auto pc) {
-                constexpr int dy = 2 * decltype(pc)::value;
-                constexpr int o0 = ((dx & 3) * 288 + (dx >> 2) * 32) / 8, o1 = o0 + G::RAW_ROW_BYTES / 8;
-                static_assert(o1 < 256, "ds_read2_b64 offsets are 8-bit");
-                f32x4 t2;
-                asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(t2) : "v"(raw2[RB ? 1 : 0][dy / 2]), "i"(o0), "i"(o1));
-                v[dx * 6 + dy] = f32x2{t2[0], t2[1]};
-                v[dx * 6 + dy + 1] = f32x2{t2[2], t2[3]};
-            }, std::make_integer_sequence<int, 3>{});
-        } else {
-            static_for([&](auto dyc) {
-                constexpr int dy = decltype(dyc)::value;
-                constexpr int off = RB + dy * G::RAW_ROW_BYTES + (dx & 3) * 288 + (dx >> 2) * 32;
-                v[dx * 6 + dy] = lds_rd64<off>(dy < 4 ? rawA : rawB);
-            }, std::make_integer_sequence<int, 6>{});
-        }
+        static_for([&](auto dyc) {
+            constexpr int dy = decltype(dyc)::value;
+            constexpr int off = RB + dy * G::RAW_ROW_BYTES + (dx & 3) * 288 + (dx >> 2) * 32;
+            v[dx * 6 + dy] = lds_rd64<off>(dy < 4 ? rawA : rawB);
+        }, std::make_integer_sequence<int, 6>{});
     };
     // U fragments of position batch b (= transform column k = b: positions r*6 + b, r = 0..5) from the U buffer at `ub`
     auto read_u_batch = [&](unsigned ub, auto bc, auto slotc) {
@@ -636,74 +370,35 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         static_for([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             // ---- gap b: U batch b is needed now; younger LDS reads = the patch column requested in run b-1's mini gap
-            if constexpr (F43_U1 == 0) {
-                if constexpr (b <= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                else if constexpr (F43_RD2 == 1) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                if constexpr (b < 5) read_u_batch(ub, std::integral_constant<int, b + 1>{}, std::integral_constant<int, (b + 1) & 1>{});
-            }
+            if constexpr (b <= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            if constexpr (b < 5) read_u_batch(ub, std::integral_constant<int, b + 1>{}, std::integral_constant<int, (b + 1) & 1>{});
             // ---- run b: 24 MFMAs, with ONE mini gap in the middle for the patch column (issued in the gap, behind the U reads, it
             // measured 1-2 % slower: profiles/r04_f43_store_study.txt) that also carries the chunk's LDS-DMA requests — wave w issues all of its 19 in
             // run w: the four waves of the CU share one address unit, requests issued at the same time queue behind each other
             static_for([&](auto rc) {
                 constexpr int r = decltype(rc)::value, pos = r * 6 + b;
                 constexpr int step = b * 6 + r;                  // issue order of the 36 position steps of a chunk
-                if constexpr (F43_U1 == 1 && step + 3 < NPOS) read_u1(ub, std::integral_constant<int, step + 3>{});
                 auto dma_req = [&](auto nc) {                    // request n of the chunk: 0..9 the halo, 10..18 the U block
                     constexpr int n = decltype(nc)::value;
-                    if constexpr (n < G::RAW_IT) bufld16_rs(rs_r, rdst + (n * NT + wave * 64) * 16, asrc_of(n), rsoff);
+                    if constexpr (n < G::RAW_IT) bufld16_rs(rs_r, rdst + (n * NT + wave * 64) * 16, asrc[n], rsoff);
                     else if constexpr (n < G::RAW_IT + G::U_IT) bufld16_rs(rs_u, udst + ((n - G::RAW_IT) * NT + wave * 64) * 16, tid * 16, usoff + (n - G::RAW_IT) * NT * 16);
                 };
-                if constexpr (F43_DMA == 1) {
-                    if constexpr (step < G::RAW_IT + G::U_IT) { if (!(ABL & 1)) dma_req(std::integral_constant<int, step>{}); }
-                } else if constexpr (F43_DMA >= 6 && F43_DMA <= 8) {      // request n at step n * SPAN / 19: the 19 requests evenly over the first SPAN steps
-                    constexpr int SPAN = F43_DMA == 6 ? 28 : (F43_DMA == 7 ? 36 : 24), NREQ = G::RAW_IT + G::U_IT;
+                {      // request n at step n * 28 / 19: the chunk's 19 requests evenly over its first 28 position steps (the CU's L2 -> LDS
+                       // path sustains 13-20 B/clock and the kernel needs 76 KB per ~7 000-clock chunk: a request issued into a full
+                       // queue stalls the wave, and with one wave per SIMD that is lost MFMA time; profiles/r05_f43_timeline.txt)
+                    constexpr int SPAN = 28, NREQ = G::RAW_IT + G::U_IT;
                     constexpr int n = (step * NREQ + SPAN - 1) / SPAN;
                     if constexpr (n < NREQ && (n * SPAN) / NREQ == step) { if (!(ABL & 1)) dma_req(std::integral_constant<int, n>{}); }
-                } else if constexpr (F43_DMA == 2) {
-                    static_for([&](auto wc) {
-                        constexpr int k = step - 5 * decltype(wc)::value;
-                        if constexpr (k >= 0 && k < 10) {
-                            if (!(ABL & 1) && wave == decltype(wc)::value) { dma_req(std::integral_constant<int, 2 * k>{}); dma_req(std::integral_constant<int, 2 * k + 1>{}); }
-                        }
-                    }, std::make_integer_sequence<int, 4>{});
-                } else if constexpr (F43_DMA == 3) {
-                    static_for([&](auto wc) {
-                        constexpr int n = step - 4 * decltype(wc)::value;
-                        if constexpr (n >= 0 && n < G::RAW_IT + G::U_IT) { if (!(ABL & 1) && wave == decltype(wc)::value) dma_req(std::integral_constant<int, n>{}); }
-                    }, std::make_integer_sequence<int, 4>{});
                 }
                 if constexpr (r == 3) {
                     if constexpr (b >= 1) { if (!last) read_patch_col(RBt{}, std::integral_constant<int, b - 1>{}); }
-                    if constexpr (b < 4 && F43_DMA == 0) {
-                        if (!(ABL & 1) && wave == b) {
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int i = 0; i < G::RAW_IT; ++i) bufld16_rs(rs_r, rdst + (i * NT + wave * 64) * 16, asrc_of(i), rsoff);
-#pragma unroll
-                            for (int i = 0; i < G::U_IT; ++i) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
                 }
                 constexpr bool AG = pos < NAG;
                 f32x4 (&ac)[2] = *[&]() -> f32x4 (*)[2] { if constexpr (AG) return &accA[pos]; else return &accV[pos - NAG]; }();
-                if constexpr (F43_U1 == 1) {
-                    // U(step) is complete when only the reads issued after it are outstanding: the U reads of the next
-                    // min(3, 35 - step) steps and — if a patch column went out in steps step-3 .. step — its pieces
-                    constexpr int NU = (35 - step) < 3 ? (35 - step) : 3;
-                    constexpr int PN = F43_RD2 == 1 ? 3 : 6;
-                    constexpr bool PATCH = (step >= 9) && ((step - 3) % 6 <= 3);      // some p in {step-3 .. step} with p % 6 == 3, p >= 9
-                    if constexpr (PATCH) {
-                        if (last) asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(NU) : "memory");
-                        else asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(NU + PN) : "memory");
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(NU) : "memory");
-                    }
-                }
                 const f32x2 vv = v[b * 6 + r];
-                const f32x4 uu = F43_U1 == 1 ? u1[step & 3] : ur[b & 1][r];
+                const f32x4 uu = ur[b & 1][r];
                 // A operand = the patch (D row = tile), B operand = U (D column = cout row): see the epilogue for why
                 if constexpr (FIRST) { mfma_zero<AG>(ac[0], vv[0], uu[0]); mfma_zero<AG>(ac[1], vv[0], uu[2]); }
                 else { mfma_acc<AG>(ac[0], vv[0], uu[0]); mfma_acc<AG>(ac[1], vv[0], uu[2]); }
@@ -716,33 +411,12 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         // registers), see the item loop.
         if (!last) read_patch_col(RBt{}, std::integral_constant<int, 5>{});
         tick(1);
-        if constexpr (F43_TAIL == 1) {
-            if (!last && !(ABL & 8)) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return v[decltype(nc)::value * 6 + decltype(jc)::value]; });
-            }
-            tick(5);
-        }
         if (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         tick(3);
         if (!last) {
-            if constexpr (F43_DMA == 5) {      // all 19 requests of chunk c+1 in one burst right behind the barrier (no MFMA, no LDS read around them)
-                auto hk = dma_hook5(c + 1);
-                static_for([&](auto nc) { hk(nc); }, std::make_integer_sequence<int, G::RAW_IT + G::U_IT>{});
-            }
-            auto rd_u0 = [&]() {
-                if constexpr (F43_U1 == 1) read_u1_first(ubn);
-                else read_u_batch(ubn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-            };
-            if constexpr (F43_UMID == 0) rd_u0();
-            if constexpr (F43_TAIL == 1) {
-                if (!(ABL & 8)) f43_in6<PK>([&](auto nc, auto jc) -> f32x2& { return v[decltype(jc)::value * 6 + decltype(nc)::value]; });
-            } else if constexpr (F43_UMID == 1) {
-                if (!(ABL & 8)) full_transform(v, dma_hook(c + 1, true), rd_u0); else rd_u0();
-            } else {
-                if (!(ABL & 8)) full_transform(v, dma_hook(c + 1, true), [] {});
-            }
+            read_u_batch(ubn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            if (!(ABL & 8)) full_transform(v);
         }
         tick(5);
     };
@@ -750,20 +424,11 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     // first tiles of an item whose predecessor did not request them (the workgroup's first item)
     auto next_patch = [&]() {        // the item's raw(0) patch + first U batch -> registers, then V(0)
         static_for([&](auto dxc) { read_patch_col(std::integral_constant<int, 0>{}, dxc); }, std::make_integer_sequence<int, 6>{});
-        auto rd_u0 = [&]() {
-            if constexpr (F43_U1 == 1) read_u1_first(offU);
-            else read_u_batch(offU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        };
-        if constexpr (F43_UMID == 0) rd_u0();
+        read_u_batch(offU, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         // every wave has read raw(0) before any wave's chunk 0 requests raw(2) into the same buffer
         if (!(ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (F43_DMA == 5) {
-            auto hk = dma_hook5(0);
-            static_for([&](auto nc) { hk(nc); }, std::make_integer_sequence<int, G::RAW_IT + G::U_IT>{});
-        }
-        if constexpr (F43_UMID == 1) { if (!(ABL & 8)) full_transform(v, dma_hook(0, true), rd_u0); else rd_u0(); }      // chunk 0's requests (F43_DMA == 4)
-        else { if (!(ABL & 8)) full_transform(v, dma_hook(0, true), [] {}); }
+        if (!(ABL & 8)) full_transform(v);
     };
     if (have) {
         stage_raw(0);

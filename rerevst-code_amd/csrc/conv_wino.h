@@ -47,14 +47,6 @@
 // TENTH position: conv1x1(up(x)) = up(conv1x1(x)) is one more GEMM on V[0][0] = x[i][j], the centre pixel the
 // upsample-fused transform already holds, with the shortcut weights in the U slot; its output is the low-resolution
 // tensor that conv2's epilogue adds (E_RES_UPS).
-// WINO_DMA_SPREAD: 1 = conv_wino_k issues a chunk's LDS-DMA requests evenly over its position iterations (0: one U and one raw
-// request per iteration from the first on, round 1-4); tools/upw_bench.hip builds both
-#ifndef WINO_DMA_SPREAD
-#define WINO_DMA_SPREAD 0
-#endif
-#ifndef WINO_DMA_TAIL        // iterations at the end of a chunk that carry no request (the last one must land before the chunk barrier)
-#define WINO_DMA_TAIL 2
-#endif
 
 template <int NW, int UPS, int SC = 0>
 struct WinoGeo {
@@ -389,21 +381,9 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
-                if constexpr (WINO_DMA_SPREAD == 1 && G::U_IT >= G::RAW_IT) {
-                    // the chunk's U_IT + RAW_IT requests evenly over its NPU iterations (U, raw alternating while there are raw
-                    // ones): the CU's L2 -> LDS path sustains 13-20 B/clock and a request issued into a full queue stalls the
-                    // issuing wave (profiles/r05_f43_timeline.txt) — two per iteration at the chunk's start is twice that rate
-                    constexpr int T = G::U_IT + G::RAW_IT;
-                    static_for([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        if constexpr ((k * (NPU - WINO_DMA_TAIL)) / T == i) {
-                            constexpr bool RAW = k < 2 * G::RAW_IT && (k & 1);
-                            constexpr int j = k < 2 * G::RAW_IT ? k / 2 : k - G::RAW_IT;
-                            if constexpr (RAW) bufld16_rs(j == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (j * NT + wave * 64) * 16, asrc[j], rsoff);
-                            else bufld16_rs(j == G::U_IT - 1 ? rs_ul : rs_u, udst + (j * NT + wave * 64) * 16, tid * 16, usoff + j * NT * 16);
-                        }
-                    }, std::make_integer_sequence<int, T>{});
-                } else {
+                // one U and one raw request per iteration from the first on (spread evenly over the chunk, as conv_f43_k paces them, measured +-0
+                // with two waves per SIMD in flight: profiles/r05_wino_dma_spread.txt)
+                {
                     if constexpr (i < G::U_IT) bufld16_rs(i == G::U_IT - 1 ? rs_ul : rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
                     if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
                 }

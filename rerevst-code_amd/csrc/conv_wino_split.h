@@ -212,18 +212,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_split_k(const ConvP p) {
             else lds_release2<S::younger(i)>(u[i & 3][0], u[i & 3][1]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(WSPLIT_ABL & 1)) {
-                if constexpr (WINO_DMA_SPREAD == 1) {      // the chunk's U_IT + RAW_IT requests evenly over its eight iterations (conv_wino.h)
-                    constexpr int T = G::U_IT + G::RAW_IT, NITER = 8;
-                    static_for([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        if constexpr ((k * (NITER - WINO_DMA_TAIL)) / T == i) {
-                            constexpr bool RAW = k < 2 * G::RAW_IT && (k & 1);
-                            constexpr int j = k < 2 * G::RAW_IT ? k / 2 : k - G::RAW_IT;
-                            if constexpr (RAW) bufld16_rs(j == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (j * NT + wave * 64) * 16, asrc[j], rsoff);
-                            else bufld16_rs(rs_u, udst + (j * NT + wave * 64) * 16, tid * 16, usoff + j * NT * 16);
-                        }
-                    }, std::make_integer_sequence<int, T>{});
-                } else {
+                {
                     if constexpr (i < G::U_IT) bufld16_rs(rs_u, udst + (i * NT + wave * 64) * 16, tid * 16, usoff + i * NT * 16);
                     if constexpr (i < G::RAW_IT) bufld16_rs(i == G::RAW_IT - 1 ? rs_rl : rs_r, rdst + (i * NT + wave * 64) * 16, asrc[i], rsoff);
                 }
