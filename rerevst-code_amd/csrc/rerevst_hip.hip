@@ -131,7 +131,7 @@ struct rrv_ctx {
     // The sets live in CONTIGUOUS arrays (set i = base + i * stride): a launch whose images carry their own blended state
     // (rrv_transfer_features_batch) passes the first set and the strides, the kernels index by image.
     static constexpr int MS_GROUP_MAX = 16;      // multi-style frames per launch sequence (each with its own blended state set)
-    static constexpr int N_SETS = 2 * MS_GROUP_MAX;      // two groups in flight (6.3 MB per set: state blob + folded KernelFilter weights)
+    static constexpr int N_SETS = 2 * MS_GROUP_MAX;      // two groups in flight.  9.9 MB per set (state blob + three KernelFilters' folded raw and packed weights), 316 MB of the 288 GB per handle, allocated once by rrv_finalize_weights
     struct StateSet { float* active = nullptr; ConvW fold_down[3], fold_up[3]; } sets[N_SETS];
     StateSet* cur = &sets[0];
     int state_images = 0;                        // > 0: the launch's images 0..state_images-1 use sets cur, cur+1, .. (per-image state)
@@ -192,9 +192,10 @@ struct rrv_ctx {
     struct GraphKey {
         int H = 0, W = 0; const void* d_in = nullptr; const void* d_out = nullptr; int f43_mode = 0; unsigned f43_layers = 0; int grid_share = 0;
         const void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;      // workspace identity: encoder c11, decoder o2, split-K parts, pre-clamp tap
+        bool illcond = false; unsigned direct_layers = 0;      // everything else the captured kernel choice depends on (use_f43's conditioning guard, the direct-form layers)
         bool operator==(const GraphKey& o) const {
             return H == o.H && W == o.W && d_in == o.d_in && d_out == o.d_out && f43_mode == o.f43_mode && f43_layers == o.f43_layers &&
-                   grid_share == o.grid_share && p0 == o.p0 && p1 == o.p1 && p2 == o.p2 && p3 == o.p3;
+                   grid_share == o.grid_share && p0 == o.p0 && p1 == o.p1 && p2 == o.p2 && p3 == o.p3 && illcond == o.illcond && direct_layers == o.direct_layers;
         }
     };
     struct GraphEntry { GraphKey key; hipGraphExec_t exec = nullptr; unsigned stamp = 0; bool used = false; };
@@ -223,6 +224,12 @@ namespace {
 
 int fail(rrv_handle h, int code, const std::string& msg) { h->err = msg; return code; }
 int dmalloc(rrv_handle h, void** p, size_t bytes);
+
+// Captured one-frame launch sequences (RRV_GRAPH=1) point into the plans' tensors: whatever frees or rebuilds a plan drops them
+void free_graphs(rrv_handle h) {
+    for (auto& row : h->graphs)
+        for (auto& g : row) { if (g.exec) (void)hipGraphExecDestroy(g.exec); g = rrv_ctx::GraphEntry{}; }
+}
 
 int sync_all(rrv_handle h) {
     for (int i = 0; i < RRV_MAX_SLOTS; ++i)
@@ -794,6 +801,7 @@ void enc_free(EncPlan& e) {
 int enc_plan(rrv_handle h, EncPlan& e, int B, int H, int W) {      // grow-only in B: a plan made for more images serves fewer
     if (e.B >= B && e.H == H && e.W == W && e.c41.p) return RRV_OK;
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "image too large ((H+2)*(W+2)*64 must be < 2^31)");
+    free_graphs(h);
     enc_free(e);
     const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
     auto build = [&]() -> int {
@@ -886,6 +894,7 @@ void dec_free(rrv_handle h, DecPlan& d) {
 }
 int dec_plan(rrv_handle h, DecPlan& d, int B, int H, int W) {       // complete or empty, as enc_plan
     if (d.B >= B && d.H == H && d.W == W && d.pre) return RRV_OK;
+    free_graphs(h);
     dec_free(h, d);
     const int H8 = H / 8, W8 = W / 8, H4 = H / 4, W4 = W / 4, H2 = H / 2, W2 = W / 2;
     auto build = [&]() -> int {
@@ -1064,7 +1073,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
     if (!graphable) {
         RCHK(body());
     } else {
-        auto key_now = [&]() { return rrv_ctx::GraphKey{H, W, d_in, d_out, h->f43_mode, h->f43_layers, h->grid_share, e.c11.p, d.o2.p, d.dpart.p, d.pre}; };
+        auto key_now = [&]() { return rrv_ctx::GraphKey{H, W, d_in, d_out, h->f43_mode, h->f43_layers, h->grid_share, e.c11.p, d.o2.p, d.dpart.p, d.pre, h->illcond, h->direct_layers}; };
         const rrv_ctx::GraphKey key = key_now();
         rrv_ctx::GraphEntry* ge = nullptr;
         for (auto& g : h->graphs[slot]) if (g.used && g.key == key) ge = &g;
@@ -1556,11 +1565,6 @@ int rrv_create(int device, rrv_handle* out) {
     if (const char* e = getenv("RRV_GRAPH")) h->use_graph = atoi(e) != 0;
     *out = h;
     return RRV_OK;
-}
-
-static void free_graphs(rrv_handle h) {
-    for (auto& row : h->graphs)
-        for (auto& g : row) { if (g.exec) (void)hipGraphExecDestroy(g.exec); g = rrv_ctx::GraphEntry{}; }
 }
 
 static void free_plans(rrv_handle h) {
@@ -2467,7 +2471,11 @@ int rrv_generate_content_features_batch(rrv_handle h, const uint8_t* frames, int
     int n_res = 0;
     while (n_res < B && h->feat_bytes + ((size_t)(n_res + 1) * img + slack) * sizeof(float) <= h->feat_cap) ++n_res;
     const int id0 = (int)h->features.size();
+    const size_t bytes0 = h->feat_bytes, blocks0 = h->feat_blocks.size();
     float* arena = nullptr;
+    // Everything from here on either completes or is undone: a failed allocation / launch must not leave
+    // valid-looking feature ids over a zero-filled or half-encoded arena for a later add_patch / transfer_features to use.
+    auto work = [&]() -> int {
     if (n_res) {
         RCHK(dmalloc(h, (void**)&arena, ((size_t)n_res * img + slack) * sizeof(float)));
         h->feat_blocks.push_back(arena);
@@ -2534,6 +2542,19 @@ int rrv_generate_content_features_batch(rrv_handle h, const uint8_t* frames, int
     const int rs = sync_all(h);
     if (rc == RRV_OK) rc = rs;
     if (rc == RRV_OK && h->debug) rc = debug_verify(h, "generate_content_features_batch");
+    return rc;
+    };
+    const int rc = work();
+    if (rc != RRV_OK) {
+        const std::string why = h->err;
+        (void)sync_all(h);
+        (void)hipGetLastError();
+        h->features.resize((size_t)id0);
+        while (h->feat_blocks.size() > blocks0) { (void)hipFree(h->feat_blocks.back()); h->feat_blocks.pop_back(); }
+        h->feat_bytes = bytes0;
+        for (int i = 0; i < B; ++i) feature_ids[i] = -1;
+        h->err = why;
+    }
     return rc;
 }
 

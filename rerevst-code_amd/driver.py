@@ -338,7 +338,7 @@ def stylize_files_multistyle(model, style_paths, frame_paths, out_dir, video_pat
 
         def flush():
             if group:
-                feats.extend(batch_encode(group) if batch_encode and len(group) > 1 else [model.generate_content_features(g) for g in group])
+                feats.extend(batch_encode(group) if batch_encode else [model.generate_content_features(g) for g in group])      # (a group of one too: every frame of a video through ONE entry, one encoder arithmetic)
                 group.clear()
         for i in range(n):
             f = look.popleft().result()

@@ -124,6 +124,32 @@ def test_config2_thirty_two_frames_per_launch_vs_oracle(pkg, weights, oracle, vi
     s.close()
 
 
+def test_1024_single_style_four_frames_per_launch_vs_oracle(pkg, weights, oracle, video):
+    """The north star's third resolution as `bench.py --size 1024` runs it (VERDICT r5 #2 ii): white-noise 1024 x 1024 frames
+    padded to 1152 x 1152, one style, FOUR frames per launch (one sub-batch of rrv_transfer_batch at this size), default
+    kernel choice; the state of the 300-frame video's 38 sampled frames.  Frames 0 and 3 of the launch, pre-clamp and image,
+    against the oracle."""
+    pad = lambda i: video.reflect_pad(pkg.synth_frame(i, 1024, 1024, kind="noise"), 1152, 1152)
+    s = pkg.Stylization(weights, cuda=True)
+    s.prepare_style(pkg.synth_style(512, 512, kind="noise", seed=7))
+    s.clean()
+    for i in video.sample_indices(300):
+        s.add(pkg.synth_frame(i, 1024, 1024, kind="noise"))
+    s.compute()
+    o = oracle.Stylization(weights)
+    o.set_state(s.get_state())
+    frames = np.stack([pad(1 + i) for i in range(4)])
+    out = np.array(s.transfer_batch(frames))
+    pres = {k: np.array(s.preclamp(1152, 1152, image=k)) for k in (0, 3)}
+    with fixed_kernels(s):
+        assert not np.array_equal(s.transfer_batch(frames), out)         # four 1152 x 1152 frames per launch: the rule picks conv_f43_k
+    np.testing.assert_array_equal(s.transfer_batch(frames), out)
+    for k in (0, 3):
+        ref = _pre_check(oracle, o, frames[k], pres[k], "1024 x 1024 frame %d of 4, default kernel choice, pre-clamp" % k)
+        _img_check(out[k], ref, "1024 x 1024 frame %d of 4, default kernel choice" % k, strict=True)
+    s.close()
+
+
 def test_every_entry_in_the_default_mode_vs_oracle(pkg, weights, oracle, video):
     """The boundary's entries with the DEFAULT kernel choice (their bit-identity to each other is tested with a fixed choice
     in test_gpu_boundary.py): one frame per call, batched (pageable and page-locked), look-ahead tickets (a quarter of the

@@ -374,6 +374,13 @@ def test_command_line_driver_end_to_end(tmp_path, pkg, weights):
     for i in range(10):      # default kernel choice: the driver's chunks and stylize_video's batches may pick different kernels per launch, so uint8 ties may round apart
         got = D.read_image_bgr(str(tmp_path / "out" / ("f%03d.png" % i)))
         assert np.abs(got.astype(np.int32) - D.to_uint8(ref[i]).astype(np.int32)).max() <= 1
+    with fixed_kernels():    # one kernel family on both sides: the same arithmetic whatever the chunking — byte for byte
+        D.main(["--style", str(tmp_path / "style.png"), "--frames", str(src / "*.png"), "--checkpoint", "synthetic", "--out", str(tmp_path / "out0")])
+        s = pkg.Stylization(weights, cuda=True)
+        ref0 = V.stylize_video(s, frames, style)
+        s.close()
+    for i in range(10):
+        np.testing.assert_array_equal(D.read_image_bgr(str(tmp_path / "out0" / ("f%03d.png" % i))), D.to_uint8(ref0[i]))
     avi = open(str(tmp_path / "v.avi"), "rb").read()
     assert avi.count(b"00dc") >= 20          # 10 chunks + 10 index entries
 
@@ -410,6 +417,13 @@ def test_command_line_driver_two_ranks_on_one_gpu(tmp_path, pkg):
         a, b = D.read_image_bgr(str(tmp_path / "o2" / nm)), D.read_image_bgr(str(tmp_path / "o1" / nm))
         assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= (0 if exact else 1)
     assert open(str(tmp_path / "v2.avi"), "rb").read().count(b"00dc") >= 22
+    if not exact:            # ... and byte for byte with one kernel family pinned on both runs
+        env0 = dict(env, RRV_F43="0")
+        for gpus, out in (("2", "p2"), ("1", "p1")):
+            r = subprocess.run(common + ["--gpus", gpus, "--out", str(tmp_path / out)], cwd=root, env=env0, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        for nm in names:
+            np.testing.assert_array_equal(D.read_image_bgr(str(tmp_path / "p2" / nm)), D.read_image_bgr(str(tmp_path / "p1" / nm)))
 
 
 @pytest.mark.parametrize("hw", [(203, 141), (77, 90), (15, 9)])

@@ -12,6 +12,18 @@ field (mean / std / min / max / filters / style moments), the pre-clamp network 
 Default inputs are the reference's own default inputs (inputs/plum_flower.jpg, inputs/ambush_4/*.png) as stored, PNG
 encoded, in tests/golden/real_default.npz.  Exit status 0 = every margin <= 1.0 (inside the bound), 1 = something is
 above its bound, 2 = could not run.  This is a checker (it imports the oracle); nothing of the product does.
+
+    python tools/check_checkpoint.py /path/to/style_net-TIP-final.pth --full [--out margins.txt]
+
+--full is the run-book for whoever holds the released file first: the strict load report (keys found /
+missing / unexpected, dtypes), the Frobenius norms of the six dynamic 32 x 32 filters of the computed state against the
+library's conditioning guard (4 sqrt(32) = 22.6: above it the encoder stays on F(2x2,3x3), rerevst_hip.hip
+filter_conditioning), and the same flow's stylized frame in each kernel mode (rrv_set_f43 0 = F(2x2,3x3) everywhere,
+1 = the default rule, 2 = conv_f43_k on every packed layer; one frame per call and the frame inside a launch of sixteen)
+against the oracle with every convolution accumulated in float64 ("torch64": the implementation's own error alone) and
+on torch's float32 conv2d (the reference's own arithmetic).
+
+    python tools/check_checkpoint.py --make-seeded-pth /tmp/seeded.pth      # the 107-key seeded stand-in, to rehearse the run-book
 """
 import argparse
 import importlib
@@ -27,9 +39,60 @@ import state_bounds as T              # noqa: E402
 import rerevst_oracle as O            # noqa: E402  (checker only)
 
 
+def full_report(args, pkg, O, T, weights, st_hip, st_ref, padded, crop, say):
+    """--full: conditioning of the computed state against the library's guard, then the stylized frame per kernel mode."""
+    blob = np.asarray(st_hip, np.float64)
+    o0 = 4 * sum(T.NORM_CH)
+    guard = 4.0 * np.sqrt(32.0)
+    norms = [float(np.sqrt((blob[o0 + 1024 * f:o0 + 1024 * (f + 1)] ** 2).sum())) for f in range(6)]
+    ill = not (max(norms) <= guard)
+    say("\ndynamic filters of the computed state (FilterPredictor outputs), Frobenius norm against the guard 4 sqrt(32) = %.2f:" % guard)
+    say("  " + "  ".join("Filter%d.F%d %.3f" % (f // 2 + 1, f % 2 + 1, n) for f, n in enumerate(norms)))
+    say("  -> %s" % ("ILL-CONDITIONED state: the default rule keeps the seven encoder layers on F(2x2,3x3) (conv_f43_k on the decoder's three only)" if ill
+                     else "well-conditioned (every seeded / real state seen so far: 5.5 .. 5.8): the default rule may run conv_f43_k on all ten packed layers"))
+    PH, PW = padded.shape[:2]
+    o = O.Stylization(weights)
+    o.set_state(st_hip)                    # the per-frame path alone: both sides start from the HIP state
+    refs = {}
+    for be in ("torch64", "torch"):
+        O.set_conv_backend(be)
+        try:
+            refs[be] = o.transfer(padded, return_preclamp=True)[0]
+        finally:
+            O.set_conv_backend("numpy")
+    img64 = O.tensor_to_image(refs["torch64"][None])
+    def margins(pre, img):
+        pw, pmax = T.pre_worst(np.asarray(pre)[crop], refs["torch64"][crop])
+        r = np.abs(np.asarray(pre, np.float64)[crop] - refs["torch64"][crop]) / (T.PRE_ATOL + T.PRE_RTOL * np.abs(refs["torch64"][crop]))
+        d = np.abs(np.asarray(img, np.float64)[crop] - img64[crop])
+        return pw, int((r > 1).sum()), float(np.percentile(r, 99.99)), float(r.mean()), float(d.max()), int((d > T.IMG_ATOL).sum())
+    say("\nstylized frame per kernel mode against the float64-accumulated oracle (HIP state on both sides; the window the driver keeps):")
+    say("  %-58s %8s %6s %9s %8s %10s %6s" % ("", "worst", "over", "99.99th", "mean", "image", ">0.05"))
+    w32 = margins(refs["torch"], O.tensor_to_image(refs["torch"][None]))
+    say("  %-58s %8.3f %6d %9.3f %8.4f %10.4f %6d" % (("the float32 oracle itself (torch conv2d)",) + w32))
+    ok = True
+    for mode, tag in ((0, "F(2x2,3x3) everywhere"), (1, "default rule"), (2, "conv_f43_k on every packed layer")):
+        m = pkg.Stylization(weights, cuda=True, device=args.device)
+        m.set_state(st_hip)
+        m.set_f43(mode)
+        out1 = np.array(m.transfer(padded)); pre1 = np.array(m.preclamp(PH, PW))
+        many = np.array(m.transfer_batch(np.stack([padded] * 16))); pre16 = np.array(m.preclamp(PH, PW, image=7))
+        m.close()
+        for what, pre, img in (("one frame per call", pre1, out1), ("frame 7 of a launch of sixteen", pre16, many[7])):
+            r = margins(pre, img)
+            say("  %-58s %8.3f %6d %9.3f %8.4f %10.4f %6d" % (("mode %d, %s, %s" % (mode, tag, what),) + r))
+            # the small-size every-value bounds where the reference arithmetic itself keeps them, else no worse than 3x its own worst value
+            ok = ok and r[0] <= max(1.0, 3.0 * w32[0]) and r[4] <= max(T.IMG_ATOL, 3.0 * w32[4])
+    say("  -> %s" % ("every mode inside max(bound, 3 x the float32 oracle's own worst value)" if ok else "a mode LEAVES max(bound, 3 x the float32 oracle's own worst value)"))
+    return ok
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("checkpoint", help="reference state_dict (.pth, 107 keys) or an .npz with the same keys")
+    ap.add_argument("checkpoint", nargs="?", help="reference state_dict (.pth, 107 keys) or an .npz with the same keys")
+    ap.add_argument("--full", action="store_true", help="strict-load report, filter conditioning against the guard, kernel modes 0 / 1 / 2 against the float64-accumulated oracle")
+    ap.add_argument("--out", help="--full: also write the report to this file")
+    ap.add_argument("--make-seeded-pth", metavar="PATH", help="write the seeded weights as a 107-key torch state_dict (with the Vgg19.* keys the released file carries) and exit")
     ap.add_argument("--style", help="style image (default: the reference's inputs/plum_flower.jpg from tests/golden/real_default.npz)")
     ap.add_argument("--frames", nargs="+", help="frame files in order (default: the 33 ambush_4 frames' sampled subset of the golden)")
     ap.add_argument("--transfer-index", type=int, default=-1, help="which frame to stylize (default: the golden's frame 12 / the middle frame)")
@@ -40,6 +103,37 @@ def main():
     pkg = importlib.import_module("rerevst-code_amd")
     W = importlib.import_module("rerevst-code_amd.weights")
     V = importlib.import_module("rerevst-code_amd.video")
+    if args.make_seeded_pth:
+        import torch
+        sd = {k: torch.from_numpy(v.copy()) for k, v in pkg.synthetic_weights(0).items()}
+        for idx, cin, cout in W.VGG_CONVS:       # the perceptual-loss VGG the released checkpoint also carries (deleted by the reference on first use)
+            sd["Vgg19.slice.%d.weight" % idx] = torch.zeros(cout, cin, 3, 3)
+            sd["Vgg19.slice.%d.bias" % idx] = torch.zeros(cout)
+        torch.save(sd, args.make_seeded_pth)
+        print("wrote %s: %d keys" % (args.make_seeded_pth, len(sd)))
+        return 0
+    if not args.checkpoint:
+        ap.error("checkpoint required")
+    report = []
+    def say(line=""):
+        print(line, flush=True)
+        report.append(line)
+    if args.full and not args.checkpoint.endswith(".npz"):       # the strict-load report (test/framework.py:74-75: load_state_dict, strict)
+        try:
+            import torch
+            sd = torch.load(args.checkpoint, map_location="cpu")
+            table = W.weight_table()
+            missing = [k for k in table if k not in sd]
+            wrong = [k for k in table if k in sd and tuple(sd[k].shape) != tuple(table[k])]
+            extra = sorted(k for k in sd if k not in table)
+            vgg = [k for k in extra if k.startswith("Vgg19.")]
+            say("strict load of %s: %d keys in the file; the path needs %d: %d missing, %d with a wrong shape; %d further keys (%d of them Vgg19.*, the perceptual-loss network the reference deletes on first use%s)"
+                % (os.path.basename(args.checkpoint), len(sd), len(table), len(missing), len(wrong), len(extra), len(vgg),
+                   "" if len(extra) == len(vgg) else "; others: " + ", ".join(k for k in extra if not k.startswith("Vgg19."))[:200]))
+            say("dtypes: %s" % sorted({str(v.dtype) for v in sd.values()}))
+        except Exception as e:
+            print("cannot read %s: %s: %s" % (args.checkpoint, type(e).__name__, e))
+            return 2
     try:
         if args.checkpoint.endswith(".npz"):
             weights = dict(np.load(args.checkpoint))
@@ -134,6 +228,11 @@ def main():
     p1, i1 = img_margins("HIP end to end (its own state):", pre_hip, out_hip)
     p2, i2 = img_margins("HIP per-frame path, oracle state injected:", pre_inj, out_inj)
     ok = sworst <= 1.0 and max(p1, i1, p2, i2) <= 1.0
+    if args.full:
+        ok = full_report(args, pkg, O, T, weights, st_hip, st_ref, padded, crop, say) and ok
+        if args.out:
+            with open(args.out, "w") as f:
+                f.write("\n".join(report) + "\n")
     print("\nHIP %.1f s, oracle (+ injected run) %.1f s.  worst margins: state %.3f, pre-clamp %.3f, image %.3f  ->  %s" %
           (t_hip, t_ref, sworst, max(p1, p2), max(i1, i2), "PASS" if ok else "FAIL (%d state fields above the bound)" % bad))
     if not ok and max(p2, i2) <= 1.0:
