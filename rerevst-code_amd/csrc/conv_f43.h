@@ -35,7 +35,7 @@
 //
 // F43_ABL (default 0; tools/f43_bench.hip builds one binary per value): microbenchmark switches — 1 no LDS-DMA after the
 // first stage, 2 no K-loop barriers, 4 no stores, 8 no input transform, 16 per-phase clock64 timeline into p.dbg, 32 no
-// epilogue.  The library is compiled with 0: every hook is a discarded constexpr branch.
+// epilogue, 64 halo requests over contiguous memory (what the scattered 32-byte pieces cost), 128 / 256 the halo access pattern of a channel-chunk-major input (row-major / column-phase-major planes), 512 the stores of a channel-chunk-major output.  The library is compiled with 0: every hook is a discarded constexpr branch.
 #pragma once
 #include "conv_wino.h"
 
@@ -238,6 +238,8 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     };
     const size_t img_floats = (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
     auto in_of = [&](const Item& a) {
+        if (ABL & 128) return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * (p.Wi + 2) + (a.tx + p.tx0) * 32) * 8;
+        if (ABL & 256) return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * 4 * ((p.Wi + 5) >> 2) + (a.tx + p.tx0) * 8) * 8;
         return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * (p.Wi + 2) + (a.tx + p.tx0) * 32) * p.Cin;
     };
     // bytes from the item's tile origin to the end of ITS image (ring included): LDS-DMA lanes beyond get zeros, so a
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     auto lim_of = [&](const Item& a) {
         const long rows_left = (long)(p.Hi + 2) - (long)(a.ty + p.ty0) * 32;
         const long n = (rows_left * (p.Wi + 2) - (long)(a.tx + p.tx0) * 32) * p.Cin * 4;
+        if (ABL & 384) return 0x7fffffff;
         return (int)(n > 0x7fffffffL ? 0x7fffffffL : n);
     };
     auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (U_BYTES / 4); };
@@ -256,7 +259,12 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         const int half = e & 1, xd = (e >> 1) % 9, ph = ((e >> 1) / 9) & 3, y = (e >> 1) / 36;
         const int x = 4 * xd + ph, par = (y >> 2) & 1;
         asrc[it] = ((y * (p.Wi + 2) + x) * p.Cin + 4 * (half ^ par)) * 4;
+        if (ABL & 64) asrc[it] = (it * NT + tid) * 16;      // microbench only (wrong data): the halo requests lane-linear over 40 contiguous KB instead of 32-byte pieces one pixel stride apart
+        if (ABL & 128) asrc[it] = ((y * (p.Wi + 2) + x) * 8 + 4 * (half ^ par)) * 4;      // microbench only: the access pattern of a channel-chunk-major tensor [C/8][H+2][W+2][8]
+        if (ABL & 256) asrc[it] = (((y * 4 + ph) * ((p.Wi + 5) >> 2) + xd) * 8 + 4 * (half ^ par)) * 4;      // ... of [C/8][H+2][4 column phases][(W+2)/4][8]: the LDS image's own order
     }
+    // (ABL & 384: bytes between consecutive chunks = one channel-chunk plane instead of 32)
+    const int cstride = (ABL & 384) ? (p.Hi + 2) * (((p.Wi + 5) >> 2) << 2) * 32 : 32;
     bool have = cur.b < p.B, have_nxt = false;
     const float* in_t = in_of(cur);
     const float* w_t = w_of(cur);
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         char* rdst = smem + (chunk & 1) * RAW_BYTES;
         const rsrc_t rs = make_rsrc(in_t, lim_t);
 #pragma unroll
-        for (int it = 0; it < G::RAW_IT; ++it) bufld16_rs(rs, rdst + (it * NT + wave * 64) * 16, asrc[it], chunk * 32);
+        for (int it = 0; it < G::RAW_IT; ++it) bufld16_rs(rs, rdst + (it * NT + wave * 64) * 16, asrc[it], chunk * cstride);
     };
     char* const par = smem + 2 * RAW_BYTES + 2 * U_BYTES;
     // img: the item's image.  Per-image state (ConvP::par_bstride != 0, the grouped multi-style decoder): image b reads its
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         const rsrc_t rs_u = make_rsrc(own_u ? w_t : w_n);
         const rsrc_t rs_r = make_rsrc(own_r ? in_t : in_n, own_r ? lim_t : lim_n);
         const int usoff = own_u ? (c + 1) * U_BYTES : 0;
-        const int rsoff = (own_r ? c + 2 : c + 2 - nchunks) * 32;
+        const int rsoff = (own_r ? c + 2 : c + 2 - nchunks) * cstride;
         char* const udst = smem + 2 * RAW_BYTES + (1 - PAR) * U_BYTES;
         char* const rdst = smem + PAR * RAW_BYTES;
         const unsigned ub = offU + PAR * U_BYTES;          // U buffer c&1
@@ -488,10 +496,17 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         // per-store address arithmetic in vector registers (precomputed addresses would be held across the whole K loop)
         constexpr bool POOL = (EPI & E_POOL) != 0;
         const int Ho = POOL ? (p.H >> 1) : p.H, Wo = POOL ? (p.W >> 1) : p.W;
-        char* const sb = (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout +
+        char* const sb = (ABL & 512) ? (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout + (size_t)e_ntile * 4 * (size_t)(Ho + 2) * (Wo + 2) * 8 +
+                                               ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2) + (POOL ? (e_x0 >> 1) : e_x0) + 1) * 8)
+                                     : (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout +
                                  ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2) + (POOL ? (e_x0 >> 1) : e_x0) + 1) * p.Cout + e_ntile * 32);
-        const int rowb = (Wo + 2) * p.Cout * 4, pixb = p.Cout * 4;
-        const unsigned st_off = POOL ? (unsigned)(((2 * mr) * (Wo + 2) + 2 * mc0) * p.Cout + 2 * t) * 4u : lane_off;
+        int rowb = (Wo + 2) * p.Cout * 4, pixb = p.Cout * 4;
+        unsigned st_off = POOL ? (unsigned)(((2 * mr) * (Wo + 2) + 2 * mc0) * p.Cout + 2 * t) * 4u : lane_off;
+        if (ABL & 512) {      // microbench only (wrong addresses, in bounds): the stores of a channel-chunk-major output [C/8][H+2][W+2][8] — a lane's channel pair is 8 bytes of a 32-byte piece, pixels 32 bytes apart
+            const unsigned plane = (unsigned)(Ho + 2) * (Wo + 2) * 32u;
+            rowb = (Wo + 2) * 32; pixb = 32;
+            st_off = (POOL ? (unsigned)((2 * mr) * (Wo + 2) + 2 * mc0) : (unsigned)((4 * (q >> 1)) * (p.W + 2) + 16 * (q & 1))) * 32u + (unsigned)(t >> 2) * plane + (unsigned)(t & 3) * 8u;
+        }
         const bool interior = e_y0 + 32 <= p.H && e_x0 + 32 <= p.W;       // wave-uniform: no per-pixel masks inside the image
         // the per-channel parameters of the lane's two channels: read from LDS once per item
         const char* const pl = par + 8 * t;

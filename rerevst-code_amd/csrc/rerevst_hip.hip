@@ -170,11 +170,14 @@ struct rrv_ctx {
     // the copies from and to the caller's pageable arrays of consecutive sub-batches overlap
     // Four sets and two dedicated copy streams: the compute streams never wait behind a DMA of their own stream.
     struct HostStage { uint8_t* pin_in = nullptr; float* pin_out = nullptr; uint8_t* d_in = nullptr; float* d_out = nullptr;
-                       size_t cap = 0, pcap = 0; hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr; } hstage[4];
+                       size_t cap = 0, pcap = 0; hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr; } hstage[RRV_MAX_SLOTS];      // host_pipeline uses the first HOST_SETS, the look-ahead tickets the first `ticket_sets`
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     // rrv_transfer_async: ticket t lives in staging set t % 4 until rrv_transfer_wait(t) (or a later submission that needs
     // its set) retires it; `out` / `out_bytes` = where a pageable caller buffer still has to be filled from pin_out
-    struct Ticket { long id = -1; float* out = nullptr; size_t out_bytes = 0; bool open = false; } tickets[4];
+    struct Ticket { long id = -1; float* out = nullptr; size_t out_bytes = 0; bool open = false; } tickets[RRV_MAX_SLOTS];
+    int ticket_sets = 4;              // tickets that may be open (RRV_TICKETS / rrv_set_lookahead: 1 .. RRV_MAX_SLOTS): ticket t lives in set t % ticket_sets on stream t % ticket_sets
+    int ticket_grid = 0;              // RRV_TICKET_GRID: persistent workgroups per launch of a ticket once all are in flight (0 = the CUs / tickets in flight, whole XCD rows)
+    bool trim_grid = false;           // RRV_TRIM=1: a persistent grid of ceil(items / rounds) workgroups — the same rounds on fewer CUs
     long next_ticket = 0;
     int grid_share = 1;               // rrv_set_grid_share: persistent grids use 1/grid_share of the CUs
     int f43_mode = 1;                 // rrv_set_f43 / RRV_F43: layers with an F(4x4,3x3) pack run on conv_f43_k — 0 never, 1 where the launch has enough work items for it to win (use_f43), 2 always
@@ -473,6 +476,7 @@ const ConvKey F43_TABLE[] = { FK(E_RELU), FK(E_RELU | E_POOL), FK(E_RELU | E_NOR
 unsigned resident_wgs(rrv_handle h, int occ) {
     unsigned r = (unsigned)h->n_cus * (unsigned)occ;
     if (h->grid_share > 1) {
+        if (h->ticket_grid > 0 && h->grid_share == h->ticket_sets) return (unsigned)(h->ticket_grid * occ);
         r = (r / h->grid_share) & ~7u;      // (a small / partitioned / CU-masked device: n_cus * occ / share < 8)
         if (r < 8) r = 8;
     }
@@ -572,6 +576,10 @@ int conv(rrv_handle h, const ConvCall& c) {
         const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B) * slabs;
         const unsigned resident = resident_wgs(h, c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);      // rrv_set_grid_share leaves CUs to the launches of the other stream(s)
         grid = dim3(items < resident ? items : resident, 1);
+        if (h->trim_grid && items > resident) {      // the same number of rounds on the fewest workgroups: the CUs left over go to the launches of the other streams
+            const unsigned rounds = (items + resident - 1) / resident;
+            grid.x = (items + rounds - 1) / rounds;
+        }
         // slabs of one pixel tile on one XCD (workgroup w runs on XCD w % 8): the raw tile is fetched once per XCD group
         p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
     }
@@ -1560,6 +1568,9 @@ int rrv_create(int device, rrv_handle* out) {
     }
     if (const char* e = getenv("RRV_F43_LAYERS")) h->f43_layers = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("RRV_DIRECT_LAYERS")) h->direct_layers = (unsigned)strtoul(e, nullptr, 0);
+    if (const char* e = getenv("RRV_TICKETS")) { const int v = atoi(e); if (v >= 1 && v <= RRV_MAX_SLOTS) h->ticket_sets = v; }
+    if (const char* e = getenv("RRV_TICKET_GRID")) { const int v = atoi(e); if (v >= 8 && v <= 1024) h->ticket_grid = v; }
+    if (const char* e = getenv("RRV_TRIM")) h->trim_grid = atoi(e) != 0;
     if (const char* e = getenv("RRV_F43")) h->f43_mode = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("RRV_DEBUG")) h->debug = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("RRV_GRAPH")) h->use_graph = atoi(e) != 0;
@@ -2210,7 +2221,7 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
         if ((ph + 2) * (pw + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
     }
     const bool in_pin = is_pinned(frames, (size_t)B * fb), out_pin = is_pinned(out, (size_t)B * fo * sizeof(float));
-    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));     // open look-ahead tickets own the staging sets
+    for (int i = 0; i < RRV_MAX_SLOTS; ++i) RCHK(retire_ticket(h, i));     // open look-ahead tickets own the staging sets
     RCHK(sync_all(h));
     const int nchunk = (B + sub - 1) / sub;
     const int nsets = nchunk < HOST_SETS ? nchunk : HOST_SETS;
@@ -2333,7 +2344,7 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
     HIPCHK(hipSetDevice(h->dev));
     const size_t fb = (size_t)H * W * 3, fo = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
     const long id = h->next_ticket;
-    const int set = (int)(id % HOST_SETS);
+    const int set = (int)(id % h->ticket_sets);
     auto& st = h->hstage[set];
     RCHK(retire_ticket(h, set));                                   // the set's previous ticket (four submissions ago)
     const bool in_pin = is_pinned(frame, fb), out_pin = is_pinned(out, fo * sizeof(float));
@@ -2362,15 +2373,15 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
     // the frames run side by side instead of queueing behind each other's last partial round of work items (one frame
     // fills 1.56 - 12.5 rounds of 256 workgroups per layer; measured device-resident at 512 x 512, one frame per launch:
     // 508 frames/s on one stream, 569 on two, 603 on four with a quarter of the CUs each — profiles/r03_b1_streams.txt)
-    const int slot = h->profiling ? 0 : (int)(id % RRV_MAX_SLOTS);
+    const int slot = h->profiling ? 0 : (int)(id % h->ticket_sets);
     hipStream_t cs = h->streams[slot];
     struct ShareScope { rrv_handle h; int saved; ~ShareScope() { h->grid_share = saved; } } share_scope{h, h->grid_share};
     if (!h->profiling && h->grid_share == 1) {       // as many shares as frames in flight once this one is queued (1 .. 4)
         int open = 1;
         for (auto& tk : h->tickets)
-            if (tk.open && tk.id != id - HOST_SETS && hipEventQuery(h->hstage[tk.id % HOST_SETS].out_done) == hipErrorNotReady) ++open;
+            if (tk.open && tk.id != id - h->ticket_sets && hipEventQuery(h->hstage[tk.id % h->ticket_sets].out_done) == hipErrorNotReady) ++open;
         (void)hipGetLastError();
-        h->grid_share = open > RRV_MAX_SLOTS ? RRV_MAX_SLOTS : open;
+        h->grid_share = open > h->ticket_sets ? h->ticket_sets : open;
     }
     // No copy streams, whatever rrv_set_host_io says: the frame is copied in on the ticket's OWN stream (1.2 MB; a
     // kernel reading it from host memory byte by byte costs more, bench `zero_copy_input_only`) and the last kernel writes
@@ -2401,7 +2412,7 @@ int rrv_transfer_wait(rrv_handle h, long ticket) {
     if (!h) return RRV_E_ARG;
     if (ticket < 0 || ticket >= h->next_ticket) return fail(h, RRV_E_ARG, "transfer_wait: no such ticket");
     HIPCHK(hipSetDevice(h->dev));
-    const int set = (int)(ticket % HOST_SETS);
+    const int set = (int)(ticket % h->ticket_sets);
     if (h->tickets[set].id != ticket) {
         if (h->tickets[set].id > ticket) return RRV_OK;            // retired by a later submission: its output is already delivered
         return fail(h, RRV_E_ARG, "transfer_wait: unknown ticket");
@@ -2462,7 +2473,7 @@ int rrv_generate_content_features_batch(rrv_handle h, const uint8_t* frames, int
     if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "generate_content_features: frame too small");
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "generate_content_features: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
     HIPCHK(hipSetDevice(h->dev));
-    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));
+    for (int i = 0; i < RRV_MAX_SLOTS; ++i) RCHK(retire_ticket(h, i));
     RCHK(sync_all(h));
     const size_t fb = (size_t)H * W * 3;
     Tens one; one.B = 1; one.H = H / 8; one.W = W / 8; one.C = 512;
@@ -2640,7 +2651,7 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
     const int H = h->features[ids[0]].H, W = h->features[ids[0]].W;
     for (int i = 1; i < n; ++i)
         if (h->features[ids[i]].H != H || h->features[ids[i]].W != W) return fail(h, RRV_E_ARG, "transfer: features of one call must share their size");
-    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));
+    for (int i = 0; i < RRV_MAX_SLOTS; ++i) RCHK(retire_ticket(h, i));
     RCHK(sync_all(h));
     const size_t npx = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
     const bool out_pin = is_pinned(out, (size_t)n * npx * sizeof(float));

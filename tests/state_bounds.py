@@ -103,56 +103,68 @@ def pre_worst(got, ref):
     return float((err / (PRE_ATOL + PRE_RTOL * np.abs(ref))).max()), float(err.max())
 
 
-# ---- full-size rule (round 5) ----------------------------------------------------------------------------------------
+# ---- full-size rule (round 5; limits re-set in round 6 from the measured tail) ---------------------------------------------
 # At a BASELINE configuration's full size (1.2 - 4 million values per white-noise frame) the every-value bounds above are
 # not a property a float32 evaluation of this network has.  Decoder.norm[0] multiplies ~1e-7 of rounding noise in near-dead
 # relu4_1 channels by rstd up to 4e3; where such a channel carries signal, a patch of pixels behind it lands at several
-# times the bound in EVERY float32 evaluation — against the same network with every convolution accumulated in float64
-# ("torch64") the reference's own arithmetic (the oracle on torch's float32 conv2d) sits at 2.0 - 7.4x the pre-clamp bound
-# on 5 - 51 values per frame and up to 0.08 grey levels, the library's DIRECT-form fp32-MFMA convolution on the whole
-# encoder at 9.8x / 75 values / 0.11 grey levels, F(2x2,3x3) at 2.0 - 15x, F(4x4,3x3) at 1.0 - 2.7x (which evaluation is
-# hit how hard differs from frame to frame: profiles/r05_fullsize_margin.txt).  So at full size the HIP path is held,
-# against the float64-accumulated oracle (= its own error alone), to
-#   * a strict bound on what is typical: mean error / bound <= FULL_MEAN, the 99.99th percentile <= FULL_PCT_LIMIT;
-#   * a bound on the tail RELATIVE to the reference arithmetic's own tail on the same frame: values outside the every-value
-#     bound <= max(FULL_OVER_FRAC of all, 4 x the float32 oracle's count), worst value <= max(FULL_WORST, 3 x its worst)
-#     (image: 10 x its count, 3 x its worst) — no looser than what the reference's own float32 evaluation does there.
-FULL_OVER_FRAC = 1e-5       # 12 of a 640 x 640 x 3 output
-FULL_PCT, FULL_PCT_LIMIT = 99.99, 0.5
-FULL_MEAN = 0.03
-FULL_WORST = 4.0            # x the pre-clamp bound; image: x IMG_ATOL
+# times the bound in EVERY float32 evaluation, measured against the same network with every convolution accumulated in
+# float64 ("torch64": the error of the evaluation under test alone).  Which evaluation is hit how hard is a draw per frame.
+# The tail, measured over ALL 128 frames of bench.py's first step (white-noise 640 x 640, sixteen per launch, the bench's
+# B = 38 state: tools/fullsize_tail.py -> profiles/r06_fullsize_tail.txt), maxima over the frames:
+#                                   worst / bound   values outside   99.99th pct   mean     image max |d|   values > 0.05
+#   the library, default choice          2.96        16 (1.3e-5)        0.436      0.0144      0.0765        2 (in 1 frame of 128)
+#   the reference's own arithmetic       7.40        52 (4.2e-5)        0.650      0.0236      0.0825        9 (in 1 frame)
+#     (the oracle on torch's float32 conv2d)
+#   the library, F(2x2,3x3) everywhere  15.29       142 (1.2e-4)        1.092      0.0108      0.2427       75 (3 frames)
+# So at full size the HIP path is held, per kernel family, to ABSOLUTE limits = those maxima with ~1.3x headroom — no clause
+# relative to the float32 oracle's own tail any more (the round-5 rule let the library reach ~45x where the
+# oracle sat at 15x).  The DEFAULT choice — what ships and what bench.py times — additionally keeps the stated image
+# tolerance on every value in every frame the suite tests (`strict`; 127 of the 128 frames keep it, none of the tested ones
+# is the 128th).  Small frames and every reference golden keep the every-value bounds above.
+FULL_PCT = 99.99
+FULL_LIMITS = {
+    #            mean error / bound, 99.99th percentile, share of values outside the bound, worst value / bound, values beyond IMG_ATOL, image max |d|
+    "default": dict(mean=0.02, pct=0.55, over_frac=2e-5, worst=4.0, img_over=4, img_worst=0.10),
+    "f22":     dict(mean=0.02, pct=1.40, over_frac=1.6e-4, worst=20.0, img_over=100, img_worst=0.32),
+}
 
 
-def pre_full_size(got, ref32, ref64, what="pre-clamp"):
-    """Pre-clamp side of the full-size rule above.  `ref32`: the oracle with its convolutions on torch's float32 conv2d;
-    `ref64`: with every convolution accumulated in float64.  Returns (worst, values over the bound, 99.99th percentile, mean,
-    the float32 oracle's own worst, its values over the bound) of error / bound."""
+def pre_full_size(got, ref32, ref64, what="pre-clamp", family="default"):
+    """Pre-clamp side of the full-size rule above.  `ref64`: the oracle with every convolution accumulated in float64;
+    `ref32`: its convolutions on torch's float32 conv2d (reported beside the result, not part of the rule).  `family`:
+    "default" (the library's kernel choice) or "f22" (F(2x2,3x3) everywhere).  Returns (worst, values over the bound, 99.99th
+    percentile, mean, the float32 oracle's own worst, its values over the bound) of error / bound."""
+    L = FULL_LIMITS[family]
     r64 = np.asarray(ref64, np.float64)
     bound = PRE_ATOL + PRE_RTOL * np.abs(r64)
     mine = np.abs(np.asarray(got, np.float64) - r64) / bound
     theirs = np.abs(np.asarray(ref32, np.float64) - r64) / bound
     worst, over, p, mean = float(mine.max()), int((mine > 1.0).sum()), float(np.percentile(mine, FULL_PCT)), float(mine.mean())
-    t_worst, t_over, t_p = float(theirs.max()), int((theirs > 1.0).sum()), float(np.percentile(theirs, FULL_PCT))
-    assert mean <= FULL_MEAN, "%s: mean error / bound %.4f (limit %.2f)" % (what, mean, FULL_MEAN)
-    assert p <= max(FULL_PCT_LIMIT, 2.0 * t_p), "%s: %.2fth percentile of error / bound is %.3f (limit %.2f; the float32 oracle itself: %.3f)" % (what, FULL_PCT, p, FULL_PCT_LIMIT, t_p)
-    allowed = max(int(FULL_OVER_FRAC * mine.size), 4 * t_over)
+    t_worst, t_over = float(theirs.max()), int((theirs > 1.0).sum())
+    assert mean <= L["mean"], "%s: mean error / bound %.4f (limit %.2f)" % (what, mean, L["mean"])
+    assert p <= L["pct"], "%s: %.2fth percentile of error / bound is %.3f (limit %.2f)" % (what, FULL_PCT, p, L["pct"])
+    allowed = int(L["over_frac"] * mine.size)
     assert over <= allowed, "%s: %d of %d values outside the bound (allowed %d; the float32 oracle itself: %d)" % (what, over, mine.size, allowed, t_over)
-    assert worst <= max(FULL_WORST, 3.0 * t_worst), "%s: worst value at %.2fx the bound from the float64-accumulated oracle (the float32 oracle itself: %.2fx)" % (what, worst, t_worst)
+    assert worst <= L["worst"], "%s: worst value at %.2fx the bound from the float64-accumulated oracle (limit %.1fx; the float32 oracle itself: %.2fx)" % (what, worst, L["worst"], t_worst)
     return worst, over, p, mean, t_worst, t_over
 
 
-def img_full_size(got, ref, what="image", ref32=None):
-    """Image side of the full-size rule: `ref` = the float64-accumulated oracle's image, `ref32` (optional) the float32
-    oracle's.  Returns (max |d|, values beyond IMG_ATOL)."""
+def img_full_size(got, ref, what="image", ref32=None, family="default", strict=False):
+    """Image side of the full-size rule: `ref` = the float64-accumulated oracle's image.  strict: every value within IMG_ATOL
+    (the stated tolerance); else the family's measured limits.  `ref32` (the float32 oracle's image) is only reported.
+    Returns (max |d|, values beyond IMG_ATOL)."""
+    L = FULL_LIMITS[family]
     d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
     worst, over = float(d.max()), int((d > IMG_ATOL).sum())
-    t_worst, t_over = 0.0, 0
+    theirs = ""
     if ref32 is not None:
         t = np.abs(np.asarray(ref32, np.float64) - np.asarray(ref, np.float64))
-        t_worst, t_over = float(t.max()), int((t > IMG_ATOL).sum())
-    allowed = max(int(FULL_OVER_FRAC * d.size), 10 * t_over)
-    assert over <= allowed, "%s: %d of %d values beyond %.2f grey levels (allowed %d; the float32 oracle itself: %d)" % (what, over, d.size, IMG_ATOL, allowed, t_over)
-    assert worst <= max(FULL_WORST * IMG_ATOL, 3.0 * t_worst), "%s: max |d| %.3f grey levels (the float32 oracle itself: %.3f)" % (what, worst, t_worst)
+        theirs = "; the float32 oracle itself: max |d| %.3f, %d beyond" % (float(t.max()), int((t > IMG_ATOL).sum()))
+    if strict:
+        assert over == 0, "%s: %d of %d values beyond %.2f grey levels, max |d| %.3f%s" % (what, over, d.size, IMG_ATOL, worst, theirs)
+        return worst, over
+    assert over <= L["img_over"], "%s: %d of %d values beyond %.2f grey levels (allowed %d%s)" % (what, over, d.size, IMG_ATOL, L["img_over"], theirs)
+    assert worst <= L["img_worst"], "%s: max |d| %.3f grey levels (limit %.2f%s)" % (what, worst, L["img_worst"], theirs)
     return worst, over
 
 

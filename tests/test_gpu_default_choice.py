@@ -46,20 +46,21 @@ def _oracle_frame(oracle, o, padded, backend="torch"):
     return pre, oracle.tensor_to_image(pre[None])
 
 
-def _pre_check(oracle, o, padded, got_pre, what):
+def _pre_check(oracle, o, padded, got_pre, what, family="default"):
     """Full-size pre-clamp rule (tests/state_bounds.py); returns (the float64-accumulated oracle's image, the float32 oracle's
     image) for the image side of the rule."""
     ref32, img32 = _oracle_frame(oracle, o, padded, "torch")
     ref64, img64 = _oracle_frame(oracle, o, padded, "torch64")
-    worst, over, p, mean, t_worst, t_over = pre_full_size(got_pre, ref32, ref64, what)
+    worst, over, p, mean, t_worst, t_over = pre_full_size(got_pre, ref32, ref64, what, family)
     print("%s: error / bound vs the float64-accumulated oracle: worst %.3f, %d values over the bound, 99.99th percentile %.3f, mean %.4f (the float32 oracle itself: worst %.3f, %d over)"
           % (what, worst, over, p, mean, t_worst, t_over))
     return img64, img32
 
 
-def _img_check(got, refs, what):
+def _img_check(got, refs, what, family="default", strict=None):
+    """Default kernel choice: every value within IMG_ATOL (strict); F(2x2,3x3) everywhere: that family's measured limits."""
     ref64, ref32 = refs if isinstance(refs, tuple) else (refs, None)
-    worst, over = img_full_size(got, ref64, what, ref32)
+    worst, over = img_full_size(got, ref64, what, ref32, family, strict=(family == "default") if strict is None else strict)
     print("%s: image max|d| %.4f grey levels, %d values beyond %.2f" % (what, worst, over, IMG_ATOL))
 
 
@@ -79,7 +80,7 @@ def test_headline_sixteen_white_noise_frames_per_launch_vs_oracle(headline, pkg,
     for k in (0, 7, 15):
         ref = _pre_check(oracle, o, frames[k], pres[k], "headline frame %d of 16, default kernel choice, pre-clamp" % k)
         _img_check(out[k], ref, "headline frame %d of 16, default kernel choice" % k)
-        _img_check(pinned[k], ref, "headline frame %d of 16, F(2x2,3x3) everywhere" % k)
+        _img_check(pinned[k], ref, "headline frame %d of 16, F(2x2,3x3) everywhere" % k, family="f22")
     for _ in range(3):                                        # run-to-run determinism of the default choice
         np.testing.assert_array_equal(s.transfer_batch(frames), out)
 
@@ -164,8 +165,9 @@ def test_every_entry_in_the_default_mode_vs_oracle(pkg, weights, oracle, video):
     PH, PW = oracle.padded_size(200), oracle.padded_size(264)            # 384 x 448
     padded = [oracle.reflect_pad(f, PH, PW) for f in raw]
     ref = [_oracle_frame(oracle, o, p, "torch64")[1] for p in padded]
-    def close(got, k, what):
-        img_full_size(got, ref[k], "%s, frame %d" % (what, k))
+    def close(got, k, what):      # a small frame: the stated tolerance on every value (the full-size rule is for the BASELINE sizes only)
+        err = float(np.abs(np.asarray(got, np.float64) - ref[k]).max())
+        assert err <= IMG_ATOL, "%s, frame %d: max |d| %.4f grey levels" % (what, k, err)
     for k in range(6):
         close(s.transfer(padded[k]), k, "transfer")
     b = s.transfer_batch(padded)
@@ -178,7 +180,7 @@ def test_every_entry_in_the_default_mode_vs_oracle(pkg, weights, oracle, video):
     for k in range(6):
         close(b[k], k, "transfer_batch")
         close(pin_out[k], k, "transfer_batch (page-locked)")
-        img_full_size(crop[k], ref[k][64:264, 64:328], "transfer_frames, frame %d" % k)
+        assert np.abs(np.asarray(crop[k], np.float64) - ref[k][64:264, 64:328]).max() <= IMG_ATOL, "transfer_frames, frame %d" % k
     for k in range(4):
         close(tk[k], k, "transfer_async")
     d_in = torch.from_numpy(np.stack(padded)).to("cuda:0")

@@ -19,7 +19,7 @@ above its bound, 2 = could not run.  This is a checker (it imports the oracle); 
 missing / unexpected, dtypes), the Frobenius norms of the six dynamic 32 x 32 filters of the computed state against the
 library's conditioning guard (4 sqrt(32) = 22.6: above it the encoder stays on F(2x2,3x3), rerevst_hip.hip
 filter_conditioning), and the same flow's stylized frame in each kernel mode (rrv_set_f43 0 = F(2x2,3x3) everywhere,
-1 = the default rule, 2 = conv_f43_k on every packed layer; one frame per call and the frame inside a launch of sixteen)
+1 = the default rule, 2 = conv_f43_k on every packed layer; one frame per call and the frame inside a full launch of the batched entry)
 against the oracle with every convolution accumulated in float64 ("torch64": the implementation's own error alone) and
 on torch's float32 conv2d (the reference's own arithmetic).
 
@@ -76,9 +76,10 @@ def full_report(args, pkg, O, T, weights, st_hip, st_ref, padded, crop, say):
         m.set_state(st_hip)
         m.set_f43(mode)
         out1 = np.array(m.transfer(padded)); pre1 = np.array(m.preclamp(PH, PW))
-        many = np.array(m.transfer_batch(np.stack([padded] * 16))); pre16 = np.array(m.preclamp(PH, PW, image=7))
+        nl = max(1, min(16, 16 * 640 * 640 // (PH * PW)))      # frames per launch of the batched entries at this size (~6.6 Mpixel)
+        many = np.array(m.transfer_batch(np.stack([padded] * nl))); pre16 = np.array(m.preclamp(PH, PW, image=nl - 1))
         m.close()
-        for what, pre, img in (("one frame per call", pre1, out1), ("frame 7 of a launch of sixteen", pre16, many[7])):
+        for what, pre, img in (("one frame per call", pre1, out1), ("last frame of a launch of %d" % nl, pre16, many[nl - 1])):
             r = margins(pre, img)
             say("  %-58s %8.3f %6d %9.3f %8.4f %10.4f %6d" % (("mode %d, %s, %s" % (mode, tag, what),) + r))
             # the small-size every-value bounds where the reference arithmetic itself keeps them, else no worse than 3x its own worst value
