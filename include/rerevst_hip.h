@@ -39,7 +39,7 @@ enum {
  * (test/style_network_global.py:37-40,148,171,330).  Layout documented in DESIGN.md. */
 #define RRV_STATE_FLOATS 17536
 #define RRV_MAX_STYLES 8
-#define RRV_MAX_SLOTS 8
+#define RRV_MAX_SLOTS 4
 
 /* Stylization.__init__ (test/framework.py:57-78): picks the device and builds the model.
  * `device` is the HIP device ordinal. */

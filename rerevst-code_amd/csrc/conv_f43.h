@@ -35,7 +35,7 @@
 //
 // F43_ABL (default 0; tools/f43_bench.hip builds one binary per value): microbenchmark switches — 1 no LDS-DMA after the
 // first stage, 2 no K-loop barriers, 4 no stores, 8 no input transform, 16 per-phase clock64 timeline into p.dbg, 32 no
-// epilogue, 64 halo requests over contiguous memory (what the scattered 32-byte pieces cost), 128 / 256 the halo access pattern of a channel-chunk-major input (row-major / column-phase-major planes), 512 the stores of a channel-chunk-major output.  The library is compiled with 0: every hook is a discarded constexpr branch.
+// epilogue, 64 halo requests over contiguous memory (what the scattered 32-byte pieces cost).  (The halo access pattern and the stores of a channel-chunk-major tensor were measured the same way — ABL 128 / 256 / 512 in commit f074ee2, profiles/r06_f43_layout.txt — and became the LAY template parameter below.)  The library is compiled with 0: every hook is a discarded constexpr branch.
 #pragma once
 #include "conv_wino.h"
 
@@ -193,9 +193,18 @@ __device__ __forceinline__ void f43_out(const f32x2 m0, const f32x2 m1, const f3
           [kb] "i"(f43_bits(F43_B)), [kb2] "i"(f43_bits(F43_B2)), [kb3] "i"(f43_bits(F43_B3)));
 }
 
-template <int EPI>
+// LAY: tensor layouts.  0: input and output are ring-layout NHWC.  Bit 0: the INPUT is channel-chunk-major ("P8":
+// [B][Cin/8][Hi+2][Wi+2][8] — image b, chunk k is an 8-channel ring-layout image of its own, zero ring included); bit 1: the
+// OUTPUT is.  Round 6: a chunk's halo out of an NHWC tensor is 2 312 separate 32-byte pieces one pixel stride apart — every
+// 1 KB LDS-DMA request touches 32 cache lines — and that, not the byte count, is what the L2 -> LDS path charges for: the
+// same bytes from contiguous memory run the kernel 12-19 % faster (profiles/r06_f43_layout.txt).  Out of a P8 plane a halo
+// row is 1 088 contiguous bytes.  The data that lands in LDS is the same byte for byte (also past the image's right edge
+// and last rows), so the results of the two layouts are bit-identical; the host picks P8 for the tensors between two
+// conv_f43_k launches (rerevst_hip.hip: run_encoder) and keeps NHWC wherever another kernel reads or writes.
+template <int EPI, int LAY = 0>
 __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     static_assert(!(EPI & E_RES), "same-resolution residuals are not needed by the layers this kernel serves");
+    constexpr bool INP8 = (LAY & 1) != 0, OUTP8 = (LAY & 2) != 0;
     using G = F43Geo;
     constexpr int ABL = F43_ABL;      // microbenchmark switches; 0 in the library
     constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, NT = G::NT, NPOS = G::NPOS;
@@ -238,16 +247,16 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     };
     const size_t img_floats = (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
     auto in_of = [&](const Item& a) {
-        if (ABL & 128) return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * (p.Wi + 2) + (a.tx + p.tx0) * 32) * 8;
-        if (ABL & 256) return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * 4 * ((p.Wi + 5) >> 2) + (a.tx + p.tx0) * 8) * 8;
-        return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * (p.Wi + 2) + (a.tx + p.tx0) * 32) * p.Cin;
+        return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * (p.Wi + 2) + (a.tx + p.tx0) * 32) * (INP8 ? 8 : p.Cin);
     };
+    // floats from one 8-channel chunk of a pixel to the next: 8 inside an NHWC pixel, one plane in P8 (added to the descriptor's
+    // BASE there, so that `lim` below — the bytes to the end of the tile's own plane — bounds every chunk alike)
+    const size_t plane_floats = (size_t)(p.Hi + 2) * (p.Wi + 2) * 8;
     // bytes from the item's tile origin to the end of ITS image (ring included): LDS-DMA lanes beyond get zeros, so a
     // tile that overruns the image's last rows never sees the next image (a frame's arithmetic is the same in any batch)
     auto lim_of = [&](const Item& a) {
         const long rows_left = (long)(p.Hi + 2) - (long)(a.ty + p.ty0) * 32;
-        const long n = (rows_left * (p.Wi + 2) - (long)(a.tx + p.tx0) * 32) * p.Cin * 4;
-        if (ABL & 384) return 0x7fffffff;
+        const long n = (rows_left * (p.Wi + 2) - (long)(a.tx + p.tx0) * 32) * (INP8 ? 8 : p.Cin) * 4;
         return (int)(n > 0x7fffffffL ? 0x7fffffffL : n);
     };
     auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (U_BYTES / 4); };
@@ -258,13 +267,9 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         if (e >= G::RAW_PIECES) e = 0;
         const int half = e & 1, xd = (e >> 1) % 9, ph = ((e >> 1) / 9) & 3, y = (e >> 1) / 36;
         const int x = 4 * xd + ph, par = (y >> 2) & 1;
-        asrc[it] = ((y * (p.Wi + 2) + x) * p.Cin + 4 * (half ^ par)) * 4;
+        asrc[it] = ((y * (p.Wi + 2) + x) * (INP8 ? 8 : p.Cin) + 4 * (half ^ par)) * 4;
         if (ABL & 64) asrc[it] = (it * NT + tid) * 16;      // microbench only (wrong data): the halo requests lane-linear over 40 contiguous KB instead of 32-byte pieces one pixel stride apart
-        if (ABL & 128) asrc[it] = ((y * (p.Wi + 2) + x) * 8 + 4 * (half ^ par)) * 4;      // microbench only: the access pattern of a channel-chunk-major tensor [C/8][H+2][W+2][8]
-        if (ABL & 256) asrc[it] = (((y * 4 + ph) * ((p.Wi + 5) >> 2) + xd) * 8 + 4 * (half ^ par)) * 4;      // ... of [C/8][H+2][4 column phases][(W+2)/4][8]: the LDS image's own order
     }
-    // (ABL & 384: bytes between consecutive chunks = one channel-chunk plane instead of 32)
-    const int cstride = (ABL & 384) ? (p.Hi + 2) * (((p.Wi + 5) >> 2) << 2) * 32 : 32;
     bool have = cur.b < p.B, have_nxt = false;
     const float* in_t = in_of(cur);
     const float* w_t = w_of(cur);
@@ -279,9 +284,9 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     };
     auto stage_raw = [&](int chunk) {
         char* rdst = smem + (chunk & 1) * RAW_BYTES;
-        const rsrc_t rs = make_rsrc(in_t, lim_t);
+        const rsrc_t rs = make_rsrc(INP8 ? in_t + chunk * plane_floats : in_t, lim_t);
 #pragma unroll
-        for (int it = 0; it < G::RAW_IT; ++it) bufld16_rs(rs, rdst + (it * NT + wave * 64) * 16, asrc[it], chunk * cstride);
+        for (int it = 0; it < G::RAW_IT; ++it) bufld16_rs(rs, rdst + (it * NT + wave * 64) * 16, asrc[it], INP8 ? 0 : chunk * 32);
     };
     char* const par = smem + 2 * RAW_BYTES + 2 * U_BYTES;
     // img: the item's image.  Per-image state (ConvP::par_bstride != 0, the grouped multi-style decoder): image b reads its
@@ -367,9 +372,10 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         // slots carry the NEXT item's U(0), raw(0), raw(1) (nchunks is even)
         const bool own_u = c + 1 < nchunks, own_r = c + 2 < nchunks;
         const rsrc_t rs_u = make_rsrc(own_u ? w_t : w_n);
-        const rsrc_t rs_r = make_rsrc(own_r ? in_t : in_n, own_r ? lim_t : lim_n);
+        const int rchunk = own_r ? c + 2 : c + 2 - nchunks;
+        const rsrc_t rs_r = make_rsrc(INP8 ? (own_r ? in_t : in_n) + rchunk * plane_floats : (own_r ? in_t : in_n), own_r ? lim_t : lim_n);
         const int usoff = own_u ? (c + 1) * U_BYTES : 0;
-        const int rsoff = (own_r ? c + 2 : c + 2 - nchunks) * cstride;
+        const int rsoff = INP8 ? 0 : rchunk * 32;
         char* const udst = smem + 2 * RAW_BYTES + (1 - PAR) * U_BYTES;
         char* const rdst = smem + PAR * RAW_BYTES;
         const unsigned ub = offU + PAR * U_BYTES;          // U buffer c&1
@@ -496,13 +502,13 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         // per-store address arithmetic in vector registers (precomputed addresses would be held across the whole K loop)
         constexpr bool POOL = (EPI & E_POOL) != 0;
         const int Ho = POOL ? (p.H >> 1) : p.H, Wo = POOL ? (p.W >> 1) : p.W;
-        char* const sb = (ABL & 512) ? (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout + (size_t)e_ntile * 4 * (size_t)(Ho + 2) * (Wo + 2) * 8 +
+        char* const sb = OUTP8 ? (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout + (size_t)e_ntile * 4 * (size_t)(Ho + 2) * (Wo + 2) * 8 +
                                                ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2) + (POOL ? (e_x0 >> 1) : e_x0) + 1) * 8)
                                      : (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout +
                                  ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2) + (POOL ? (e_x0 >> 1) : e_x0) + 1) * p.Cout + e_ntile * 32);
         int rowb = (Wo + 2) * p.Cout * 4, pixb = p.Cout * 4;
         unsigned st_off = POOL ? (unsigned)(((2 * mr) * (Wo + 2) + 2 * mc0) * p.Cout + 2 * t) * 4u : lane_off;
-        if (ABL & 512) {      // microbench only (wrong addresses, in bounds): the stores of a channel-chunk-major output [C/8][H+2][W+2][8] — a lane's channel pair is 8 bytes of a 32-byte piece, pixels 32 bytes apart
+        if constexpr (OUTP8) {      // [C/8][Ho+2][Wo+2][8]: a lane's channel pair (2t, 2t+1 of the slab) is 8 bytes of the 32-byte piece of chunk 4 ntile + t/4; pixels 32 bytes apart
             const unsigned plane = (unsigned)(Ho + 2) * (Wo + 2) * 32u;
             rowb = (Wo + 2) * 32; pixb = 32;
             st_off = (POOL ? (unsigned)((2 * mr) * (Wo + 2) + 2 * mc0) : (unsigned)((4 * (q >> 1)) * (p.W + 2) + 16 * (q & 1))) * 32u + (unsigned)(t >> 2) * plane + (unsigned)(t & 3) * 8u;

@@ -71,6 +71,7 @@ struct ConvP {
     // (floats; all 0 = one state / one weight set for the whole launch).
     int par_bstride, bias_bstride;
     long long w_bstride;
+    int out_p8;        // conv_wino_k (upsample-fused form): `out` is channel-chunk-major [B][Cout/8][H+2][W+2][8] — what conv_f43_k<.., LAY & 1> reads (conv_f43.h)
 };
 
 template <int BN>

@@ -26,6 +26,7 @@ struct FirstP {
     // frame and padded pixel (y, x) reads source pixel (reflect(y - pad_top), reflect(x - pad_left)), edge-inclusive
     // (cv2.BORDER_REFLECT = numpy 'symmetric').  src_H == 0: img already has the padded geometry.
     int src_H, src_W, pad_top, pad_left;
+    int p8;               // 1: `out` is channel-chunk-major [B][8 chunks][H+2][W+2][8] (conv_f43.h LAY: what conv1_2 on conv_f43_k reads 12-19 % faster); same values
 };
 
 // symmetric (edge-inclusive) reflection of t into [0, n), any distance
@@ -68,6 +69,35 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
             s_g[i] = d[2] * 0.299f + d[1] * 0.587f + d[0] * 0.114f;   // :493 (sic)
         }
         __syncthreads();
+        if (p.p8) {      // the same arithmetic under another thread mapping: thread = (half of a chunk: 4 channels, pixel column, chunk), a loop over the 16 rows —
+                         // consecutive lanes store consecutive 16-byte pieces: 32 lanes = 16 pixels x 32 bytes = 512 contiguous bytes of one chunk plane
+            const int half = tid & 1, pc = (tid >> 1) & 15, k8 = tid >> 5, q4 = (k8 * 2 + half) * 4;
+            f32x4 w1[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w1[k] = *(const f32x4*)&p.wg[k * 64 + q4];
+            const f32x4 bias = *(const f32x4*)&p.wg[1152 + q4];
+            float* const plane = p.out + ((size_t)b * 8 + k8) * (size_t)(p.H + 2) * (p.W + 2) * 8 + ((size_t)(y0 + 1) * (p.W + 2) + x0 + pc + 1) * 8 + half * 4;
+            float g[3][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[r + 1][c] = s_g[r * 18 + pc + c];
+#pragma unroll
+            for (int prow = 0; prow < 16; ++prow) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { g[0][c] = g[1][c]; g[1][c] = g[2][c]; g[2][c] = s_g[(prow + 2) * 18 + pc + c]; }
+                f32x4 acc = bias;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc += w1[ky * 3 + kx] * g[ky][kx];
+                f32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e], 0.f);
+                __builtin_nontemporal_store(r, (f32x4*)&plane[(size_t)prow * (p.W + 2) * 8]);
+            }
+            return;
+        }
         const int q = tid & 15, prow = tid >> 4;
         f32x4 w1[9];
 #pragma unroll
@@ -119,6 +149,36 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
     }
     __syncthreads();
 
+    if (p.p8) {      // border tiles of a channel-chunk-major output: the general arithmetic below under the thread mapping of the fast path above
+        const int half = tid & 1, pc = (tid >> 1) & 15, k8 = tid >> 5, q4 = (k8 * 2 + half) * 4;
+        f32x4 w[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) w[k] = *(const f32x4*)&s_w[k * 64 + q4];
+        const f32x4 bias = *(const f32x4*)&p.bias[q4];
+        float* const plane = p.out + ((size_t)b * 8 + k8) * (size_t)(p.H + 2) * (p.W + 2) * 8 + half * 4;
+        const int x = x0 + pc;
+        for (int prow = 0; prow < 16; ++prow) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 v = *(const f32x4*)&s_in[((prow + ky) * 18 + pc + kx) * 4];
+                    const int k = (ky * 3 + kx) * 3;
+                    acc += w[k] * v[0];
+                    acc += w[k + 1] * v[1];
+                    acc += w[k + 2] * v[2];
+                }
+            const int y = y0 + prow;
+            if (y < p.H && x < p.W) {
+                f32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e], 0.f);
+                *(f32x4*)&plane[((size_t)(y + 1) * (p.W + 2) + x + 1) * 8] = r;
+            }
+        }
+        return;
+    }
     const int q = tid & 15;      // output channels 4q..4q+3
     const int prow = tid >> 4;   // pixel row inside the tile
     f32x4 w[27];

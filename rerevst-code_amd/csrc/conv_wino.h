@@ -527,6 +527,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
                     if (EPI & E_NORM2) o = e4fma(f4norm_clamp(o, m2, r2, lo2, hi2), sstd, smean);
                     if (y < p.H && x < p.W) {
                         if (ABL & 4) { if (o[0] == 123.456f) out_b[co] = o[0]; }
+                        else if (p.out_p8) *(f32x4*)(out_b + (co >> 3) * ((p.H + 2) * (p.W + 2) * 8) + ((y + 1) * (p.W + 2) + x + 1) * 8 + (co & 7)) = o;      // chunk plane co / 8: the lane's four channels are half of a pixel's 32-byte piece
                         else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
                     }
                 }

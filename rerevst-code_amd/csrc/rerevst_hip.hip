@@ -71,11 +71,16 @@ struct EncPlan {   // encoder activations for one (B, H, W)
     int B = 0, H = 0, W = 0;
     unsigned stamp = 0;     // last use (two geometries per slot, least recently used one is replaced)
     Tens c11, p1, c21, p2, c31, c32, c33, p3, c41;
+    // channel-chunk-major ("P8": [B][C/8][H+2][W+2][8], conv_f43.h LAY) twins of the tensors BETWEEN two conv_f43_k launches — and of c11, which
+    // conv_first_k can write either way — allocated on first use as ring-layout tensors of B * C/8 eight-channel images (so the
+    // debug mode's ring / guard checks cover them unchanged).  A twin and its NHWC original never mix: each keeps its own zero ring.
+    Tens q11, q1, q21, q2, q31, q32, q33;
 };
 struct DecPlan {   // per-frame decoder activations for one (B, H, W) of the FRAME batch
     int B = 0, H = 0, W = 0;
     unsigned stamp = 0;
     Tens d, f1, f2, f3, xs4, a4, o4, xs3, a3, o3, xs2, a2, o2;
+    Tens qa4, qa3, qa2;     // channel-chunk-major twins of a4 / a3 / a2 (ResidualBlock.conv1's output when conv2 runs conv_f43_k; EncPlan::q11 .. above), allocated on first use
     Tens dpart;             // [.., 32 * split]: partial sums of the split-K 512->32 KernelFilter convolution (allocated on first use)
     float* pre = nullptr;   // [H][W][3] pre-clamp tap
 };
@@ -170,19 +175,17 @@ struct rrv_ctx {
     // the copies from and to the caller's pageable arrays of consecutive sub-batches overlap
     // Four sets and two dedicated copy streams: the compute streams never wait behind a DMA of their own stream.
     struct HostStage { uint8_t* pin_in = nullptr; float* pin_out = nullptr; uint8_t* d_in = nullptr; float* d_out = nullptr;
-                       size_t cap = 0, pcap = 0; hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr; } hstage[RRV_MAX_SLOTS];      // host_pipeline uses the first HOST_SETS, the look-ahead tickets the first `ticket_sets`
+                       size_t cap = 0, pcap = 0; hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr; } hstage[4];
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     // rrv_transfer_async: ticket t lives in staging set t % 4 until rrv_transfer_wait(t) (or a later submission that needs
     // its set) retires it; `out` / `out_bytes` = where a pageable caller buffer still has to be filled from pin_out
-    struct Ticket { long id = -1; float* out = nullptr; size_t out_bytes = 0; bool open = false; } tickets[RRV_MAX_SLOTS];
-    int ticket_sets = 4;              // tickets that may be open (RRV_TICKETS / rrv_set_lookahead: 1 .. RRV_MAX_SLOTS): ticket t lives in set t % ticket_sets on stream t % ticket_sets
-    int ticket_grid = 0;              // RRV_TICKET_GRID: persistent workgroups per launch of a ticket once all are in flight (0 = the CUs / tickets in flight, whole XCD rows)
-    bool trim_grid = false;           // RRV_TRIM=1: a persistent grid of ceil(items / rounds) workgroups — the same rounds on fewer CUs
+    struct Ticket { long id = -1; float* out = nullptr; size_t out_bytes = 0; bool open = false; } tickets[4];
     long next_ticket = 0;
     int grid_share = 1;               // rrv_set_grid_share: persistent grids use 1/grid_share of the CUs
     int f43_mode = 1;                 // rrv_set_f43 / RRV_F43: layers with an F(4x4,3x3) pack run on conv_f43_k — 0 never, 1 where the launch has enough work items for it to win (use_f43), 2 always
     unsigned f43_layers = F43_DEFAULT_LAYERS;   // which of the packed layers may run on conv_f43_k (RRV_F43_LAYERS overrides: experiments / parity attribution)
     bool illcond = false;             // some computed style's state is ill-conditioned (StyleState::illcond)
+    int p8 = 3;                       // channel-chunk-major tensors in front of conv_f43_k launches (conv_f43.h LAY): bit 0 the encoder chain (EncPlan::q11 ..), bit 1 ResidualBlock.conv2's input (DecPlan::qa4 ..); RRV_P8=0: NHWC everywhere (A/B, same bits)
     bool f43_path = false;            // true inside transfer_device only: the preparation pass (prepare_style / add / compute, frame mode) always runs F(2x2,3x3)
     unsigned direct_layers = 0;       // RRV_DIRECT_LAYERS: encoder convs (bit i = vgg conv i: 1 conv1_2 .. 8 conv4_1) of the per-frame path that run the direct-form kernel
     int ms_group = 0;                 // rrv_set_multistyle_group: frames per launch sequence of rrv_transfer_features_batch (0 = by the frame size)
@@ -398,6 +401,7 @@ struct ConvCall {
     const float* bias = nullptr;   // override of the layer's bias (split K: [32 * ksplit] = the bias, then zeros)
     int par_bstride = 0, bias_bstride = 0; long long w_bstride = 0;      // per-image state (ConvP): floats between consecutive images' n1 / n2 / sty, bias, weights
     bool direct = false;           // the direct-form implicit-GEMM kernel (conv_mfma_k: 9 multiplies per output, no transform-domain rounding) instead of a Winograd form
+    bool in_p8 = false, out_p8 = false;      // conv_f43_k only: `in` / `out` is the channel-chunk-major twin (a Tens of B * C/8 eight-channel images; conv_f43.h LAY)
 };
 
 template <int BN, int TAPS, int EPI>
@@ -441,13 +445,16 @@ hipError_t wsplit_attr() {
     if (e == hipSuccess && PERIMG) e = hipFuncSetAttribute((const void*)conv_wino_split_k<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WSPLIT_SMEM_BYTES);
     return e;
 }
-template <int EPI>
+template <int EPI, int LAY = 0>
 void f43_launch(const ConvP& p, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_f43_k<EPI>), grid, dim3(F43Geo::NT), F43Geo::SMEM, s, p);
+    hipLaunchKernelGGL((conv_f43_k<EPI, LAY>), grid, dim3(F43Geo::NT), F43Geo::SMEM, s, p);
 }
-template <int EPI>
-hipError_t f43_attr() { return hipFuncSetAttribute((const void*)conv_f43_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F43Geo::SMEM); }
+template <int EPI, int LAY = 0>
+hipError_t f43_attr() { return hipFuncSetAttribute((const void*)conv_f43_k<EPI, LAY>, hipFuncAttributeMaxDynamicSharedMemorySize, F43Geo::SMEM); }
 #define FK(EPI) {32, 9, 0, EPI, &f43_launch<EPI>, "conv_f43<" #EPI ">", &f43_attr<EPI>, nullptr}
+// the same kernels on channel-chunk-major tensors (conv_f43.h LAY: bit 0 input, bit 1 output): the instantiations the per-frame path uses
+struct F43LayKey { int EPI, LAY; ConvFn fn; const char* name; AttrFn attr; };
+#define FKL(EPI, LAY) {EPI, LAY, &f43_launch<EPI, LAY>, "conv_f43<" #EPI ">", &f43_attr<EPI, LAY>}
 // F(4x4,3x3): the same-resolution 3x3 layers of the per-frame path with Cin, Cout >= 64, when the launch carries enough
 // frames (conv()).  3-6x the rounding error of F(2x2,3x3) and 1.13-1.22x its rate at 8 frames per launch.
 #define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI, 0>, "conv_wino<" #EPI ">", &wsplit_attr<EPI, 0>, nullptr}
@@ -470,13 +477,17 @@ const ConvKey WINO_TABLE[] = {
 };
 
 const ConvKey F43_TABLE[] = { FK(E_RELU), FK(E_RELU | E_POOL), FK(E_RELU | E_NORM1), FK(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2) };
+const F43LayKey F43_LAY_TABLE[] = {
+    FKL(E_RELU | E_POOL, 3), FKL(E_RELU, 3),      // conv1_2, conv2_2 / conv2_1, conv3_1 .. conv3_3: P8 in, P8 out
+    FKL(E_RELU | E_POOL, 1),                      // conv3_4: P8 in, NHWC out (conv4_1 runs the row-split kernel)
+    FKL(E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2, 1),      // ResidualBlock.conv2: P8 in (written by the upsample-fused conv1), NHWC out
+};
 
 // Persistent workgroups of a transform-domain launch: `occ` per CU, on the 1/grid_share of the CUs this launch may use
 // (rrv_set_grid_share, look-ahead tickets: whole XCD rows, never empty).  conv() sizes its grid with it and use_f43 its rounds.
 unsigned resident_wgs(rrv_handle h, int occ) {
     unsigned r = (unsigned)h->n_cus * (unsigned)occ;
     if (h->grid_share > 1) {
-        if (h->ticket_grid > 0 && h->grid_share == h->ticket_sets) return (unsigned)(h->ticket_grid * occ);
         r = (r / h->grid_share) & ~7u;      // (a small / partitioned / CU-masked device: n_cus * occ / share < 8)
         if (r < 8) r = 8;
     }
@@ -538,6 +549,15 @@ int conv(rrv_handle h, const ConvCall& c) {
         snprintf(b, sizeof b, "no conv kernel for BN=%d taps=%d ups=%d epi=%d", w.BN, w.taps, (int)c.ups, c.epi);
         return fail(h, RRV_E_ARG, b);
     }
+    const int lay = (c.in_p8 ? 1 : 0) | (c.out_p8 ? 2 : 0);
+    ConvFn lay_fn = nullptr;
+    const bool ups_p8 = lay == 2 && c.ups;      // the upsample-fused kernel writes a P8 tensor through ConvP::out_p8 (no separate instantiation)
+    if (lay && !ups_p8) {
+        if (!f43) return fail(h, RRV_E_ARG, "conv: channel-chunk-major tensors are conv_f43_k's");
+        for (const F43LayKey& e : F43_LAY_TABLE)
+            if (e.EPI == c.epi && e.LAY == lay) lay_fn = e.fn;
+        if (!lay_fn) return fail(h, RRV_E_ARG, "conv: no conv_f43_k instantiation for this layout");
+    }
     ConvP p{};
     p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W; p.Cin = w.Cin;
     p.out = c.out->p; p.H = c.H; p.W = c.W; p.Cout = w.Cout; p.B = c.B;
@@ -550,13 +570,15 @@ int conv(rrv_handle h, const ConvCall& c) {
     if (!p.wpk) return fail(h, RRV_E_ARG, "conv: weights not packed for this kernel"); p.n1 = c.n1; p.n2 = c.n2; p.sty = c.sty;
     if (c.bias) p.bias = c.bias;
     p.par_bstride = c.par_bstride; p.bias_bstride = c.bias_bstride; p.w_bstride = c.w_bstride;
+    if (ups_p8) { if (!wino) return fail(h, RRV_E_ARG, "conv: no upsample-fused kernel for this layer"); p.out_p8 = 1; }
     if ((c.par_bstride | c.bias_bstride || c.w_bstride) && !wino) return fail(h, RRV_E_ARG, "conv: per-image state needs a transform-domain kernel");
     if (ks > 1) {       // the [1 slab][Cin/16 chunks] weight pack read as [ks slabs][Cin/16/ks chunks]: slab s = input channel slice s
         p.Cin = w.Cin / ks; p.cstride = w.Cin; p.cin_slab_step = w.Cin / ks; p.Cout = 32 * ks;
     }
     if (c.res) { p.res = c.res->p; p.Hr = c.res->H; p.Wr = c.res->W; }
     p.tiles_x = (c.W + 15) / 16; p.tiles_y = (c.H + 7) / 8;
-    if (c.in->C != w.Cin || c.out->C != w.Cout * ks) return fail(h, RRV_E_ARG, "conv: channel mismatch");
+    if ((c.in_p8 ? c.in->C != 8 || c.in->B < c.B * (w.Cin / 8) : c.in->C != w.Cin) ||
+        (c.out_p8 ? c.out->C != 8 || c.out->B < c.B * (w.Cout / 8) : c.out->C != w.Cout * ks)) return fail(h, RRV_E_ARG, "conv: channel mismatch");
     const int eh = c.ups ? c.H / 2 : c.H, ew = c.ups ? c.W / 2 : c.W;
     if (c.in->H != eh || c.in->W != ew) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
@@ -576,10 +598,6 @@ int conv(rrv_handle h, const ConvCall& c) {
         const unsigned items = (unsigned)(p.tiles_x * p.tiles_y * c.B) * slabs;
         const unsigned resident = resident_wgs(h, c.ups ? WinoGeo<UPW_NW, 1>::OCC : 1);      // rrv_set_grid_share leaves CUs to the launches of the other stream(s)
         grid = dim3(items < resident ? items : resident, 1);
-        if (h->trim_grid && items > resident) {      // the same number of rounds on the fewest workgroups: the CUs left over go to the launches of the other streams
-            const unsigned rounds = (items + resident - 1) / resident;
-            grid.x = (items + rounds - 1) / rounds;
-        }
         // slabs of one pixel tile on one XCD (workgroup w runs on XCD w % 8): the raw tile is fetched once per XCD group
         p.xcd_slabs = (grid.x % 8 == 0 && (grid.x / 8) % slabs == 0) ? 1 : 0;
     }
@@ -595,7 +613,7 @@ int conv(rrv_handle h, const ConvCall& c) {
                                 (c.res ? (double)c.B * c.res->H * c.res->W * w.Cout : 0.0) + (double)w.Cout * cin * w.taps +
                                 (fuse_sc ? (double)c.B * c.in->H * c.in->W * w.Cout + (double)w.Cout * cin : 0.0));
     hipStream_t s = h->stream;
-    ConvFn fn = k->fn;
+    ConvFn fn = lay_fn ? lay_fn : k->fn;
     if (wino && !f43 && (c.par_bstride | c.bias_bstride || c.w_bstride)) {      // per-image state is a separate instantiation of the F(2x2,3x3) / upsample-fused kernels (conv_f43_k reads par_bstride itself)
         if (!k->fn_img) return fail(h, RRV_E_ARG, "conv: this layer has no per-image-state kernel");
         fn = k->fn_img;
@@ -800,7 +818,7 @@ int ensure_active(rrv_handle h) {
 
 // ---- encoder ----------------------------------------------------------------------------
 void enc_free(EncPlan& e) {
-    for (Tens* t : {&e.c11, &e.p1, &e.c21, &e.p2, &e.c31, &e.c32, &e.c33, &e.p3, &e.c41}) tfree(t);
+    for (Tens* t : {&e.c11, &e.p1, &e.c21, &e.p2, &e.c31, &e.c32, &e.c33, &e.p3, &e.c41, &e.q11, &e.q1, &e.q21, &e.q2, &e.q31, &e.q32, &e.q33}) tfree(t);
     e.B = e.H = e.W = 0;
 }
 // A plan is either complete or empty: the geometry is recorded only after every tensor exists; a failed allocation
@@ -853,11 +871,6 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
     const int H = e.H, W = e.W, B = nb;
     if (nb < 1 || nb > e.B) return fail(h, RRV_E_ARG, "run_encoder: batch does not fit the plan");
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "image too large ((H+2)*(W+2)*64 must be < 2^31)");
-    FirstP fp{d_img, H, W, B, e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16,
-              which == 0 ? h->first_wg : nullptr, pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0};
-    RCHK(launch(h, "conv_first", 2.0 * B * H * W * 27 * 64, (3.0 + 256.0) * B * H * W, [&] {
-        hipLaunchKernelGGL(conv_first_k, dim3(fp.tiles_x * fp.tiles_y * B), dim3(256), 0, h->stream, fp);
-    }));
     auto W_ = [&](int i) -> const ConvW* {
         char k[64];
         if (which == 0) snprintf(k, sizeof k, "Encoder.slice.%d", VGG_IDX[i]);
@@ -865,7 +878,49 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
         return &h->conv[k];
     };
     auto D_ = [&](int i) { return which == 0 && h->f43_path && ((h->direct_layers >> i) & 1u) != 0; };
+    // Channel-chunk-major tensors (conv_f43.h LAY) between the seven packed layers when ALL of them run conv_f43_k in this launch (the rule
+    // of use_f43 says yes for every launch with enough work items: the batched entries); any other mix keeps NHWC throughout.  The
+    // choice changes no bit of the result — conv_f43_k stages the same bytes from either layout.
+    bool p8 = which == 0 && h->f43_path && (h->p8 & 1);
+    {
+        const int lh[8] = {0, H, H / 2, H / 2, H / 4, H / 4, H / 4, H / 4}, lw[8] = {0, W, W / 2, W / 2, W / 4, W / 4, W / 4, W / 4};
+        const int le[8] = {0, E_RELU | E_POOL, E_RELU, E_RELU | E_POOL, E_RELU, E_RELU, E_RELU, E_RELU | E_POOL};
+        for (int i = 1; i <= 7 && p8; ++i) p8 = !D_(i) && use_f43(h, *W_(i), B, lh[i], lw[i], le[i], false, 0, false);
+    }
+    if (p8 && !e.q33.p) {      // first use of this plan with the chain: the twins, for as many images as the plan holds
+        const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
+        auto build = [&]() -> int {
+            RCHK(talloc(h, &e.q11, e.B * 8, H, W, 8));
+            RCHK(talloc(h, &e.q1, e.B * 8, H2, W2, 8));
+            RCHK(talloc(h, &e.q21, e.B * 16, H2, W2, 8));
+            RCHK(talloc(h, &e.q2, e.B * 16, H4, W4, 8));
+            RCHK(talloc(h, &e.q31, e.B * 32, H4, W4, 8));
+            RCHK(talloc(h, &e.q32, e.B * 32, H4, W4, 8));
+            RCHK(talloc(h, &e.q33, e.B * 32, H4, W4, 8));
+            return RRV_OK;
+        };
+        const int rc = build();
+        if (rc != RRV_OK) { for (Tens* t : {&e.q11, &e.q1, &e.q21, &e.q2, &e.q31, &e.q32, &e.q33}) tfree(t); return rc; }
+    }
+    FirstP fp{d_img, H, W, B, p8 ? e.q11.p : e.c11.p, h->first_w[which], h->first_b[which], which == 0 ? 1 : 0, (W + 15) / 16, (H + 15) / 16,
+              which == 0 ? h->first_wg : nullptr, pc ? pc->src_H : 0, pc ? pc->src_W : 0, pc ? pc->top : 0, pc ? pc->left : 0, p8 ? 1 : 0};
+    RCHK(launch(h, "conv_first", 2.0 * B * H * W * 27 * 64, (3.0 + 256.0) * B * H * W, [&] {
+        hipLaunchKernelGGL(conv_first_k, dim3(fp.tiles_x * fp.tiles_y * B), dim3(256), 0, h->stream, fp);
+    }));
     ConvCall c;
+    if (p8) {
+        auto L = [&](Tens* in, Tens* out, int i, int hh, int ww, int epi, bool out_p8) {
+            ConvCall k{in, out, W_(i), hh, ww}; k.B = B; k.epi = epi; k.in_p8 = true; k.out_p8 = out_p8;
+            return conv(h, k);
+        };
+        RCHK(L(&e.q11, &e.q1, 1, H, W, E_RELU | E_POOL, true));
+        RCHK(L(&e.q1, &e.q21, 2, H / 2, W / 2, E_RELU, true));
+        RCHK(L(&e.q21, &e.q2, 3, H / 2, W / 2, E_RELU | E_POOL, true));
+        RCHK(L(&e.q2, &e.q31, 4, e.p2.H, e.p2.W, E_RELU, true));
+        RCHK(L(&e.q31, &e.q32, 5, e.p2.H, e.p2.W, E_RELU, true));
+        RCHK(L(&e.q32, &e.q33, 6, e.p2.H, e.p2.W, E_RELU, true));
+        RCHK(L(&e.q33, &e.p3, 7, e.p2.H, e.p2.W, E_RELU | E_POOL, false));
+    } else {
     c = ConvCall{&e.c11, &e.p1, W_(1), H, W}; c.B = B; c.epi = E_RELU | E_POOL; c.direct = D_(1); RCHK(conv(h, c));
     c = ConvCall{&e.p1, &e.c21, W_(2), H / 2, W / 2}; c.B = B; c.epi = E_RELU; c.direct = D_(2); RCHK(conv(h, c));
     c = ConvCall{&e.c21, &e.p2, W_(3), H / 2, W / 2}; c.B = B; c.epi = E_RELU | E_POOL; c.direct = D_(3); RCHK(conv(h, c));
@@ -873,6 +928,7 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
     c = ConvCall{&e.c31, &e.c32, W_(5), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; c.direct = D_(5); RCHK(conv(h, c));
     c = ConvCall{&e.c32, &e.c33, W_(6), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU; c.direct = D_(6); RCHK(conv(h, c));
     c = ConvCall{&e.c33, &e.p3, W_(7), e.p2.H, e.p2.W}; c.B = B; c.epi = E_RELU | E_POOL; c.direct = D_(7); RCHK(conv(h, c));
+    }
     c = ConvCall{&e.p3, out41 ? out41 : &e.c41, W_(8), e.p3.H, e.p3.W}; c.B = B; c.epi = E_RELU | (norm0 ? E_NORM1 : 0); c.n1 = norm0; c.direct = D_(8); RCHK(conv(h, c));
     return RRV_OK;
 }
@@ -896,7 +952,7 @@ int ensure_outf(rrv_handle h, size_t floats) {
 
 // ---- per-frame decoder --------------------------------------------------------------------
 void dec_free(rrv_handle h, DecPlan& d) {
-    for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2, &d.dpart}) tfree(t);
+    for (Tens* t : {&d.d, &d.f1, &d.f2, &d.f3, &d.xs4, &d.a4, &d.o4, &d.xs3, &d.a3, &d.o3, &d.xs2, &d.a2, &d.o2, &d.dpart, &d.qa4, &d.qa3, &d.qa2}) tfree(t);
     if (d.pre) { if (h->last_pre == d.pre) h->last_pre = nullptr; (void)hipFree(d.pre); d.pre = nullptr; }
     d.B = d.H = d.W = 0;
 }
@@ -960,17 +1016,26 @@ int filter_down(rrv_handle h, const Tens* cur, DecPlan& d, int f, int B) {
 struct Win { int y0, x0, y1, x1; };     // output window in pixels, tile aligned; y1 == 0: everything
 
 int resblock_frame(rrv_handle h, int B, const char* blk, const Tens& in, Tens& xs, Tens& a, Tens& o, int n1, int n2, int nada, int sty,
-                   const Win* wa = nullptr, const Win* wo = nullptr) {
+                   const Win* wa = nullptr, const Win* wo = nullptr, Tens* qa = nullptr) {
     const float* st = h->cur->active;
     const std::string p = std::string("Decoder.") + blk;
     ConvCall c;
+    // conv2 on conv_f43_k reads its input channel-chunk-major (conv_f43.h LAY; same bits, 12 % faster): conv1 then writes the twin
+    Tens* a_in = &a;
+    bool p8 = false;
+    if (qa && (h->p8 & 2)) {
+        const ConvW& w2 = h->conv[p + ".conv2"];
+        p8 = use_f43(h, w2, B, a.H, a.W, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2, false, 0, false) && !(wo && ((wo->y0 | wo->x0 | wo->y1 | wo->x1) & 31));
+        if (p8 && (!qa->p || qa->B < a.B * (a.C / 8))) RCHK(talloc(h, qa, a.B * (a.C / 8), a.H, a.W, 8));
+        if (p8) a_in = qa;
+    }
     // conv1 behind the upsample and, in the same kernel, the 1x1 shortcut at the input resolution: up(conv1x1(x)) == conv1x1(up(x))
-    c = ConvCall{&in, &a, &h->conv[p + ".conv1"], a.H, a.W}; c.B = B; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1];
-    c.sc_out = &xs;
+    c = ConvCall{&in, a_in, &h->conv[p + ".conv1"], a.H, a.W}; c.B = B; c.ups = true; c.epi = E_LRELU | E_NORM1; c.n1 = st + SL.norm[n1];
+    c.sc_out = &xs; c.out_p8 = p8;
     if (h->state_images) c.par_bstride = RRV_STATE_FLOATS;
     if (wa) { c.wy0 = wa->y0; c.wx0 = wa->x0; c.wy1 = wa->y1; c.wx1 = wa->x1; }
     RCHK(conv(h, c));
-    c = ConvCall{&a, &o, &h->conv[p + ".conv2"], a.H, a.W}; c.B = B;
+    c = ConvCall{a_in, &o, &h->conv[p + ".conv2"], a.H, a.W}; c.B = B; c.in_p8 = p8;
     if (h->state_images) c.par_bstride = RRV_STATE_FLOATS;
     c.epi = E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2; c.n1 = st + SL.norm[n2]; c.res = &xs; c.n2 = st + SL.norm[nada]; c.sty = st + SL.sty[sty];
     if (wo) { c.wy0 = wo->y0; c.wx0 = wo->x0; c.wy1 = wo->y1; c.wx1 = wo->x1; }
@@ -1047,8 +1112,8 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         RCHK(conv(h, u));
         cur = fo[f];
     }
-    RCHK(resblock_frame(h, B, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2));
-    RCHK(resblock_frame(h, B, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1));
+    RCHK(resblock_frame(h, B, "slice4", d.f3, d.xs4, d.a4, d.o4, N_S4N1, N_S4N2, N_DEC2, 2, nullptr, nullptr, &d.qa4));
+    RCHK(resblock_frame(h, B, "slice3", d.o4, d.xs3, d.a3, d.o3, N_S3N1, N_S3N2, N_DEC3, 1, nullptr, nullptr, &d.qa3));
     // On-device crop: nothing outside the crop window is delivered, so the full-resolution layers only compute the
     // tiles the window (plus one halo pixel per 3x3 layer) needs; results inside the window are unchanged.  One level
     // down (320^2) the tile-rounded window already covers the frame for the reference's 64-pixel pad.
@@ -1071,7 +1136,7 @@ int transfer_device(rrv_handle h, const uint8_t* d_in, int B, int H, int W, floa
         }
         wa = grow(wo, 1);          // slice2.conv1 output (and, halved, the shortcut) feeding that
     }
-    RCHK(resblock_frame(h, B, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr));
+    RCHK(resblock_frame(h, B, "slice2", d.o3, d.xs2, d.a2, d.o2, N_S2N1, N_S2N2, N_DEC4, 0, roi ? &wa : nullptr, roi ? &wo : nullptr, &d.qa2));
     RCHK(run_last(h, d.o2, B, Ho, Wo, d_out, d.pre, pc, roi ? &wl : nullptr));
     return RRV_OK;
     };
@@ -1553,6 +1618,8 @@ int rrv_create(int device, rrv_handle* out) {
         if (ok && e.attr) ok = e.attr() == hipSuccess;
     for (const ConvKey& e : F43_TABLE)
         if (ok && e.attr) ok = e.attr() == hipSuccess;
+    for (const F43LayKey& e : F43_LAY_TABLE)
+        if (ok && e.attr) ok = e.attr() == hipSuccess;
     if (!ok) {
         delete h;
         return RRV_E_HIP;
@@ -1568,9 +1635,7 @@ int rrv_create(int device, rrv_handle* out) {
     }
     if (const char* e = getenv("RRV_F43_LAYERS")) h->f43_layers = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("RRV_DIRECT_LAYERS")) h->direct_layers = (unsigned)strtoul(e, nullptr, 0);
-    if (const char* e = getenv("RRV_TICKETS")) { const int v = atoi(e); if (v >= 1 && v <= RRV_MAX_SLOTS) h->ticket_sets = v; }
-    if (const char* e = getenv("RRV_TICKET_GRID")) { const int v = atoi(e); if (v >= 8 && v <= 1024) h->ticket_grid = v; }
-    if (const char* e = getenv("RRV_TRIM")) h->trim_grid = atoi(e) != 0;
+    if (const char* e = getenv("RRV_P8")) h->p8 = atoi(e) & 3;
     if (const char* e = getenv("RRV_F43")) h->f43_mode = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("RRV_DEBUG")) h->debug = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("RRV_GRAPH")) h->use_graph = atoi(e) != 0;
@@ -2221,7 +2286,7 @@ static int host_pipeline(rrv_handle h, const uint8_t* frames, int B, int H, int 
         if ((ph + 2) * (pw + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "transfer: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
     }
     const bool in_pin = is_pinned(frames, (size_t)B * fb), out_pin = is_pinned(out, (size_t)B * fo * sizeof(float));
-    for (int i = 0; i < RRV_MAX_SLOTS; ++i) RCHK(retire_ticket(h, i));     // open look-ahead tickets own the staging sets
+    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));     // open look-ahead tickets own the staging sets
     RCHK(sync_all(h));
     const int nchunk = (B + sub - 1) / sub;
     const int nsets = nchunk < HOST_SETS ? nchunk : HOST_SETS;
@@ -2344,7 +2409,7 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
     HIPCHK(hipSetDevice(h->dev));
     const size_t fb = (size_t)H * W * 3, fo = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
     const long id = h->next_ticket;
-    const int set = (int)(id % h->ticket_sets);
+    const int set = (int)(id % HOST_SETS);
     auto& st = h->hstage[set];
     RCHK(retire_ticket(h, set));                                   // the set's previous ticket (four submissions ago)
     const bool in_pin = is_pinned(frame, fb), out_pin = is_pinned(out, fo * sizeof(float));
@@ -2373,15 +2438,15 @@ int rrv_transfer_async(rrv_handle h, const uint8_t* frame, int H, int W, float* 
     // the frames run side by side instead of queueing behind each other's last partial round of work items (one frame
     // fills 1.56 - 12.5 rounds of 256 workgroups per layer; measured device-resident at 512 x 512, one frame per launch:
     // 508 frames/s on one stream, 569 on two, 603 on four with a quarter of the CUs each — profiles/r03_b1_streams.txt)
-    const int slot = h->profiling ? 0 : (int)(id % h->ticket_sets);
+    const int slot = h->profiling ? 0 : (int)(id % RRV_MAX_SLOTS);
     hipStream_t cs = h->streams[slot];
     struct ShareScope { rrv_handle h; int saved; ~ShareScope() { h->grid_share = saved; } } share_scope{h, h->grid_share};
     if (!h->profiling && h->grid_share == 1) {       // as many shares as frames in flight once this one is queued (1 .. 4)
         int open = 1;
         for (auto& tk : h->tickets)
-            if (tk.open && tk.id != id - h->ticket_sets && hipEventQuery(h->hstage[tk.id % h->ticket_sets].out_done) == hipErrorNotReady) ++open;
+            if (tk.open && tk.id != id - HOST_SETS && hipEventQuery(h->hstage[tk.id % HOST_SETS].out_done) == hipErrorNotReady) ++open;
         (void)hipGetLastError();
-        h->grid_share = open > h->ticket_sets ? h->ticket_sets : open;
+        h->grid_share = open > RRV_MAX_SLOTS ? RRV_MAX_SLOTS : open;
     }
     // No copy streams, whatever rrv_set_host_io says: the frame is copied in on the ticket's OWN stream (1.2 MB; a
     // kernel reading it from host memory byte by byte costs more, bench `zero_copy_input_only`) and the last kernel writes
@@ -2412,7 +2477,7 @@ int rrv_transfer_wait(rrv_handle h, long ticket) {
     if (!h) return RRV_E_ARG;
     if (ticket < 0 || ticket >= h->next_ticket) return fail(h, RRV_E_ARG, "transfer_wait: no such ticket");
     HIPCHK(hipSetDevice(h->dev));
-    const int set = (int)(ticket % h->ticket_sets);
+    const int set = (int)(ticket % HOST_SETS);
     if (h->tickets[set].id != ticket) {
         if (h->tickets[set].id > ticket) return RRV_OK;            // retired by a later submission: its output is already delivered
         return fail(h, RRV_E_ARG, "transfer_wait: unknown ticket");
@@ -2473,7 +2538,7 @@ int rrv_generate_content_features_batch(rrv_handle h, const uint8_t* frames, int
     if (H < 8 || W < 8) return fail(h, RRV_E_ARG, "generate_content_features: frame too small");
     if ((double)(H + 2) * (W + 2) * 64.0 >= 2147483648.0) return fail(h, RRV_E_ARG, "generate_content_features: frame too large ((H+2)*(W+2)*64 must be < 2^31)");
     HIPCHK(hipSetDevice(h->dev));
-    for (int i = 0; i < RRV_MAX_SLOTS; ++i) RCHK(retire_ticket(h, i));
+    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));
     RCHK(sync_all(h));
     const size_t fb = (size_t)H * W * 3;
     Tens one; one.B = 1; one.H = H / 8; one.W = W / 8; one.C = 512;
@@ -2651,7 +2716,7 @@ int rrv_transfer_features_batch(rrv_handle h, const int* ids, const float* wts, 
     const int H = h->features[ids[0]].H, W = h->features[ids[0]].W;
     for (int i = 1; i < n; ++i)
         if (h->features[ids[i]].H != H || h->features[ids[i]].W != W) return fail(h, RRV_E_ARG, "transfer: features of one call must share their size");
-    for (int i = 0; i < RRV_MAX_SLOTS; ++i) RCHK(retire_ticket(h, i));
+    for (int i = 0; i < HOST_SETS; ++i) RCHK(retire_ticket(h, i));
     RCHK(sync_all(h));
     const size_t npx = (size_t)(H / 8 * 8) * (W / 8 * 8) * 3;
     const bool out_pin = is_pinned(out, (size_t)n * npx * sizeof(float));

@@ -247,9 +247,9 @@ class Stylization():
         self._chk(self._lib.rrv_transfer_async(self._h, a.ctypes.data_as(C.c_void_p), H, W, out.ctypes.data_as(C.c_void_p), C.byref(t)))
         # The library owns `out` until the ticket is collected or retired: a caller that drops the ticket (an exception in
         # its loop, `prev` overwritten) must not hand the block back to the pool under a running kernel.  Submitting
-        # ticket t retired ticket t - n (n staging sets: four by default, at most RRV_MAX_SLOTS = 8), so only the last eight stay referenced here.
+        # ticket t retired ticket t - 4 (four staging sets), so only the last four stay referenced here.
         self._open[t.value] = out
-        for old in [k for k in self._open if k <= t.value - 8]:
+        for old in [k for k in self._open if k <= t.value - 4]:
             del self._open[old]
         return (t.value, out)
 

@@ -180,6 +180,40 @@ def test_f43_under_the_bounds_checked_debug_mode(pkg, weights, oracle, all_f43_l
     s.close()
 
 
+def test_channel_chunk_major_tensors_change_no_bit(pkg, weights, oracle, monkeypatch):
+    """Round 6: between the seven packed encoder layers — and from ResidualBlock.conv1 to conv2 — the activations travel
+    channel-chunk-major ([B][C/8][H+2][W+2][8]: a chunk's halo is contiguous rows instead of 2 312 scattered 32-byte pieces,
+    conv_f43.h LAY) whenever the consumer runs conv_f43_k in a launch.  conv_f43_k stages the same bytes from either layout — also past the right edge and the last rows of an image —
+    so the results must be BIT-identical to the NHWC chain (RRV_P8=0): a size with partial 32 x 32 items at every level, the
+    headline's launch shape in the default mode, the pad / crop entry and the bounds-checked debug mode."""
+    video = __import__("importlib").import_module("rerevst-code_amd.video")
+    g = load_golden("global_a")
+    small = [oracle.reflect_pad(pkg.synth_frame(720 + i, 200, 264, kind="noise"), 392, 456) for i in range(5)]      # 392 x 456: 12.25 x 14.25 items at full resolution
+    raw = [pkg.synth_frame(720 + i, 200, 264, kind="noise") for i in range(5)]
+    big = np.stack([video.reflect_pad(pkg.synth_frame(1 + i, 512, 512, kind="noise"), 640, 640) for i in range(16)])
+    res = {}
+    for p8 in ("3", "1", "0"):      # encoder chain + ResidualBlock.conv2's input (the default) / the encoder chain only / NHWC everywhere
+        monkeypatch.setenv("RRV_P8", p8)
+        s = pkg.Stylization(weights, cuda=True)
+        s.set_state(g["state"])
+        s.set_f43(2)
+        a = np.array(s.transfer_batch(small))
+        b = np.array(s.transfer_frames(raw))
+        s.set_debug(2)
+        np.testing.assert_array_equal(s.transfer_batch(small), a)            # guard bands, zero rings (the twins are ring-layout tensors of 8-channel images) and slack rows intact after every kernel
+        s.set_debug(0)
+        s.set_f43(1)
+        c = np.array(s.transfer_batch(big))
+        res[p8] = (a, b, c)
+        s.close()
+    for other in ("3", "1"):
+        for x, y in zip(res[other], res["0"]):
+            np.testing.assert_array_equal(x, y)
+    ref = oracle.Stylization(weights)
+    ref.set_state(g["state"])
+    assert np.abs(res["3"][0][2] - ref.transfer(small[2])).max() <= IMG_ATOL
+
+
 def test_f43_mode_argument_is_checked(hip, pkg):
     with pytest.raises(pkg.RRVError):
         hip.set_f43(3)
