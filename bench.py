@@ -54,8 +54,9 @@ def rocprof_name(kernel):
         return str(sum(EPI_BITS[t.strip()] for t in txt.split("|"))) if txt[:2] == "E_" else txt
     if base == "conv_wino":      # the row-split 8-wave kernel, <EPI, ABL>
         return "void conv_wino_split_k<%s, 0>(ConvP)" % epi(args)
-    if base == "conv_f43":       # F(4x4,3x3), <EPI>
-        return "void conv_f43_k<%s>(ConvP)" % epi(args)
+    if base == "conv_f43":       # F(4x4,3x3), <EPI[, LAY]>: LAY = tensor layouts (conv_f43.h; 0 = NHWC in and out)
+        e, _, lay = args.partition(",")
+        return "void conv_f43_k<%s, %s>(ConvP)" % (epi(e), lay.strip() or "0")
     if base in ("conv_upw", "conv_upw_sc"):       # conv_wino_k<EPI, ABL, waves, UPS, SC>: rerevst_hip.hip UPW_NW
         return "void conv_wino_k<%s, 0, 4, 1, %d, 0>(ConvP)" % (epi(args), 1 if base.endswith("_sc") else 0)      # last: PERIMG
     if base == "conv_mfma":

@@ -42,6 +42,9 @@
 #ifndef F43_ABL
 #define F43_ABL 0
 #endif
+#ifndef F43_SPAN
+#define F43_SPAN 28      // a chunk's 19 LDS-DMA requests are spread over its first F43_SPAN position steps (tools/f43_bench.hip sweeps it)
+#endif
 // Measured-and-lost variants of this kernel (where the LDS-DMA requests go: F43_DMA 0-5, 7, 8; F43_TAIL, F43_RD2, F43_AS, F43_UMID,
 // F43_U1; six transform lines in lockstep) are in the git history up to 0a3fa2e and in profiles/r05_f43_timeline.txt; what
 // ships: one request every 28/19 position steps, the six transform multipliers in SGPR pairs, three lines in lockstep.
@@ -201,10 +204,21 @@ __device__ __forceinline__ void f43_out(const f32x2 m0, const f32x2 m1, const f3
 // row is 1 088 contiguous bytes.  The data that lands in LDS is the same byte for byte (also past the image's right edge
 // and last rows), so the results of the two layouts are bit-identical; the host picks P8 for the tensors between two
 // conv_f43_k launches (rerevst_hip.hip: run_encoder) and keeps NHWC wherever another kernel reads or writes.
+// A P8 plane's rows are pitched W + 8 pixels with pixel x at stored column x + 4 (P8_PITCH / P8_COL0; NHWC: W + 2, x + 1): 4 pixels
+// are one 128-byte line, so tiles and their rows start on line boundaries — stores that start 32 bytes into a line run at half the
+// write bandwidth (tools/store_align_bench.hip: 3.0 against 5.8 TB/s).  Columns 0 .. 3 and W + 4 .. W + 7 stay zero: the conv padding.
+// Past the right edge of an image (W not a multiple of 32) a tile reads the zero columns and then the next row, as it does in NHWC with
+// other values there: in-image outputs agree with the NHWC chain to the last bit where every level is a multiple of 32 wide, and to
+// rounding noise of the discarded columns elsewhere.
+#ifndef P8_PAD
+#define P8_PAD 6              /* extra pixels of pitch: a P8 twin is a ring-layout tensor of width W + 6 */
+#define P8_COL0 4             /* stored column of pixel x = 0 */
+#endif
 template <int EPI, int LAY = 0>
 __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
     static_assert(!(EPI & E_RES), "same-resolution residuals are not needed by the layers this kernel serves");
     constexpr bool INP8 = (LAY & 1) != 0, OUTP8 = (LAY & 2) != 0;
+    const int WP = p.Wi + 2 + (INP8 ? P8_PAD : 0);      // input pitch in pixels
     using G = F43Geo;
     constexpr int ABL = F43_ABL;      // microbenchmark switches; 0 in the library
     constexpr int RAW_BYTES = G::RAW_BYTES, U_BYTES = G::U_BYTES, NT = G::NT, NPOS = G::NPOS;
@@ -245,18 +259,18 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         r.b += dlt.b;
         return r;
     };
-    const size_t img_floats = (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin;
-    auto in_of = [&](const Item& a) {
-        return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * (p.Wi + 2) + (a.tx + p.tx0) * 32) * (INP8 ? 8 : p.Cin);
+    const size_t img_floats = (size_t)(p.Hi + 2) * WP * p.Cin;
+    auto in_of = [&](const Item& a) {      // the tile's halo origin: stored row 32 ty, stored column 32 tx (+ P8_COL0 - 1 in a P8 plane)
+        return p.in + (size_t)a.b * img_floats + (size_t)(((a.ty + p.ty0) * 32) * WP + (a.tx + p.tx0) * 32 + (INP8 ? P8_COL0 - 1 : 0)) * (INP8 ? 8 : p.Cin);
     };
     // floats from one 8-channel chunk of a pixel to the next: 8 inside an NHWC pixel, one plane in P8 (added to the descriptor's
     // BASE there, so that `lim` below — the bytes to the end of the tile's own plane — bounds every chunk alike)
-    const size_t plane_floats = (size_t)(p.Hi + 2) * (p.Wi + 2) * 8;
+    const size_t plane_floats = (size_t)(p.Hi + 2) * WP * 8;
     // bytes from the item's tile origin to the end of ITS image (ring included): LDS-DMA lanes beyond get zeros, so a
     // tile that overruns the image's last rows never sees the next image (a frame's arithmetic is the same in any batch)
     auto lim_of = [&](const Item& a) {
         const long rows_left = (long)(p.Hi + 2) - (long)(a.ty + p.ty0) * 32;
-        const long n = (rows_left * (p.Wi + 2) - (long)(a.tx + p.tx0) * 32) * (INP8 ? 8 : p.Cin) * 4;
+        const long n = (rows_left * WP - (long)(a.tx + p.tx0) * 32 - (INP8 ? P8_COL0 - 1 : 0)) * (INP8 ? 8 : p.Cin) * 4;
         return (int)(n > 0x7fffffffL ? 0x7fffffffL : n);
     };
     auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (U_BYTES / 4); };
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         if (e >= G::RAW_PIECES) e = 0;
         const int half = e & 1, xd = (e >> 1) % 9, ph = ((e >> 1) / 9) & 3, y = (e >> 1) / 36;
         const int x = 4 * xd + ph, par = (y >> 2) & 1;
-        asrc[it] = ((y * (p.Wi + 2) + x) * (INP8 ? 8 : p.Cin) + 4 * (half ^ par)) * 4;
+        asrc[it] = ((y * WP + x) * (INP8 ? 8 : p.Cin) + 4 * (half ^ par)) * 4;
         if (ABL & 64) asrc[it] = (it * NT + tid) * 16;      // microbench only (wrong data): the halo requests lane-linear over 40 contiguous KB instead of 32-byte pieces one pixel stride apart
     }
     bool have = cur.b < p.B, have_nxt = false;
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                 {      // request n at step n * 28 / 19: the chunk's 19 requests evenly over its first 28 position steps (the CU's L2 -> LDS
                        // path sustains 13-20 B/clock and the kernel needs 76 KB per ~7 000-clock chunk: a request issued into a full
                        // queue stalls the wave, and with one wave per SIMD that is lost MFMA time; profiles/r05_f43_timeline.txt)
-                    constexpr int SPAN = 28, NREQ = G::RAW_IT + G::U_IT;
+                    constexpr int SPAN = F43_SPAN, NREQ = G::RAW_IT + G::U_IT;
                     constexpr int n = (step * NREQ + SPAN - 1) / SPAN;
                     if constexpr (n < NREQ && (n * SPAN) / NREQ == step) { if (!(ABL & 1)) dma_req(std::integral_constant<int, n>{}); }
                 }
@@ -502,16 +516,17 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         // per-store address arithmetic in vector registers (precomputed addresses would be held across the whole K loop)
         constexpr bool POOL = (EPI & E_POOL) != 0;
         const int Ho = POOL ? (p.H >> 1) : p.H, Wo = POOL ? (p.W >> 1) : p.W;
-        char* const sb = OUTP8 ? (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout + (size_t)e_ntile * 4 * (size_t)(Ho + 2) * (Wo + 2) * 8 +
-                                               ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2) + (POOL ? (e_x0 >> 1) : e_x0) + 1) * 8)
-                                     : (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout +
+        constexpr int OP = OUTP8 ? P8_PAD : 0;      // output pitch: Wo + 2 + OP pixels
+        char* const sb = OUTP8 ? (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2 + OP) * p.Cout + (size_t)e_ntile * 4 * (size_t)(Ho + 2) * (Wo + 2 + OP) * 8 +
+                                         ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2 + OP) + (POOL ? (e_x0 >> 1) : e_x0) + P8_COL0) * 8)
+                               : (char*)(p.out + (size_t)e_b * (size_t)(Ho + 2) * (Wo + 2) * p.Cout +
                                  ((size_t)((POOL ? (e_y0 >> 1) + 4 * wave : e_y0 + 8 * wave) + 1) * (Wo + 2) + (POOL ? (e_x0 >> 1) : e_x0) + 1) * p.Cout + e_ntile * 32);
         int rowb = (Wo + 2) * p.Cout * 4, pixb = p.Cout * 4;
         unsigned st_off = POOL ? (unsigned)(((2 * mr) * (Wo + 2) + 2 * mc0) * p.Cout + 2 * t) * 4u : lane_off;
         if constexpr (OUTP8) {      // [C/8][Ho+2][Wo+2][8]: a lane's channel pair (2t, 2t+1 of the slab) is 8 bytes of the 32-byte piece of chunk 4 ntile + t/4; pixels 32 bytes apart
-            const unsigned plane = (unsigned)(Ho + 2) * (Wo + 2) * 32u;
-            rowb = (Wo + 2) * 32; pixb = 32;
-            st_off = (POOL ? (unsigned)((2 * mr) * (Wo + 2) + 2 * mc0) : (unsigned)((4 * (q >> 1)) * (p.W + 2) + 16 * (q & 1))) * 32u + (unsigned)(t >> 2) * plane + (unsigned)(t & 3) * 8u;
+            const unsigned plane = (unsigned)(Ho + 2) * (Wo + 2 + OP) * 32u;
+            rowb = (Wo + 2 + OP) * 32; pixb = 32;
+            st_off = (POOL ? (unsigned)((2 * mr) * (Wo + 2 + OP) + 2 * mc0) : (unsigned)((4 * (q >> 1)) * (p.W + 2 + OP) + 16 * (q & 1))) * 32u + (unsigned)(t >> 2) * plane + (unsigned)(t & 3) * 8u;
         }
         const bool interior = e_y0 + 32 <= p.H && e_x0 + 32 <= p.W;       // wave-uniform: no per-pixel masks inside the image
         // the per-channel parameters of the lane's two channels: read from LDS once per item

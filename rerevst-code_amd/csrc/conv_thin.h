@@ -26,7 +26,7 @@ struct FirstP {
     // frame and padded pixel (y, x) reads source pixel (reflect(y - pad_top), reflect(x - pad_left)), edge-inclusive
     // (cv2.BORDER_REFLECT = numpy 'symmetric').  src_H == 0: img already has the padded geometry.
     int src_H, src_W, pad_top, pad_left;
-    int p8;               // 1: `out` is channel-chunk-major [B][8 chunks][H+2][W+2][8] (conv_f43.h LAY: what conv1_2 on conv_f43_k reads 12-19 % faster); same values
+    int p8;               // 1: `out` is channel-chunk-major [B][8 chunks][H+2][W+8][8], pixel x at column x + 4 (conv_f43.h LAY: what conv1_2 on conv_f43_k reads 12-19 % faster); same values
 };
 
 // symmetric (edge-inclusive) reflection of t into [0, n), any distance
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) w1[k] = *(const f32x4*)&p.wg[k * 64 + q4];
             const f32x4 bias = *(const f32x4*)&p.wg[1152 + q4];
-            float* const plane = p.out + ((size_t)b * 8 + k8) * (size_t)(p.H + 2) * (p.W + 2) * 8 + ((size_t)(y0 + 1) * (p.W + 2) + x0 + pc + 1) * 8 + half * 4;
+            float* const plane = p.out + ((size_t)b * 8 + k8) * (size_t)(p.H + 2) * (p.W + 8) * 8 + ((size_t)(y0 + 1) * (p.W + 8) + x0 + pc + 4) * 8 + half * 4;      // rows pitched W + 8, pixel x at column x + 4: every 512-byte run starts on a line (conv_f43.h P8_PAD / P8_COL0)
             float g[3][3];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
                 f32x4 r;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e], 0.f);
-                __builtin_nontemporal_store(r, (f32x4*)&plane[(size_t)prow * (p.W + 2) * 8]);
+                __builtin_nontemporal_store(r, (f32x4*)&plane[(size_t)prow * (p.W + 8) * 8]);
             }
             return;
         }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
 #pragma unroll
         for (int k = 0; k < 27; ++k) w[k] = *(const f32x4*)&s_w[k * 64 + q4];
         const f32x4 bias = *(const f32x4*)&p.bias[q4];
-        float* const plane = p.out + ((size_t)b * 8 + k8) * (size_t)(p.H + 2) * (p.W + 2) * 8 + half * 4;
+        float* const plane = p.out + ((size_t)b * 8 + k8) * (size_t)(p.H + 2) * (p.W + 8) * 8 + half * 4;
         const int x = x0 + pc;
         for (int prow = 0; prow < 16; ++prow) {
             f32x4 acc = bias;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_first_k(const FirstP p) {
                 f32x4 r;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e], 0.f);
-                *(f32x4*)&plane[((size_t)(y + 1) * (p.W + 2) + x + 1) * 8] = r;
+                *(f32x4*)&plane[((size_t)(y + 1) * (p.W + 8) + x + 4) * 8] = r;
             }
         }
         return;

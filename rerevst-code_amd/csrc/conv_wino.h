@@ -460,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
             continue;
         }
         // ---- output transform + fused epilogue (all in registers)
-        float* out_b = p.out + (size_t)e_b * (size_t)(p.H + 2) * (p.W + 2) * p.Cout;
+        float* out_b = p.out + (size_t)e_b * (size_t)(p.H + 2) * (p.W + 2 + (p.out_p8 ? 6 : 0)) * p.Cout;      // (a channel-chunk-major output's rows are pitched W + 8: conv_f43.h P8_PAD)
         const float* res_b = nullptr;
         if (EPI & (E_RES | E_RES_UPS)) res_b = p.res + (size_t)e_b * (size_t)(p.Hr + 2) * (p.Wr + 2) * p.Cout;
         const int yb = e_y0 + 4 * tg + 2 * tr, xb = e_x0 + 2 * tc;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
                     if (EPI & E_NORM2) o = e4fma(f4norm_clamp(o, m2, r2, lo2, hi2), sstd, smean);
                     if (y < p.H && x < p.W) {
                         if (ABL & 4) { if (o[0] == 123.456f) out_b[co] = o[0]; }
-                        else if (p.out_p8) *(f32x4*)(out_b + (co >> 3) * ((p.H + 2) * (p.W + 2) * 8) + ((y + 1) * (p.W + 2) + x + 1) * 8 + (co & 7)) = o;      // chunk plane co / 8: the lane's four channels are half of a pixel's 32-byte piece
+                        else if (p.out_p8) *(f32x4*)(out_b + (co >> 3) * ((p.H + 2) * (p.W + 8) * 8) + ((y + 1) * (p.W + 8) + x + 4) * 8 + (co & 7)) = o;      // chunk plane co / 8: the lane's four channels are half of a pixel's 32-byte piece
                         else *(f32x4*)(out_b + ((y + 1) * (p.W + 2) + x + 1) * p.Cout + co) = o;
                     }
                 }

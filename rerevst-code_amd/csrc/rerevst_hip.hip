@@ -71,8 +71,8 @@ struct EncPlan {   // encoder activations for one (B, H, W)
     int B = 0, H = 0, W = 0;
     unsigned stamp = 0;     // last use (two geometries per slot, least recently used one is replaced)
     Tens c11, p1, c21, p2, c31, c32, c33, p3, c41;
-    // channel-chunk-major ("P8": [B][C/8][H+2][W+2][8], conv_f43.h LAY) twins of the tensors BETWEEN two conv_f43_k launches — and of c11, which
-    // conv_first_k can write either way — allocated on first use as ring-layout tensors of B * C/8 eight-channel images (so the
+    // channel-chunk-major ("P8": [B][C/8][H+2][W+8][8], conv_f43.h LAY) twins of the tensors BETWEEN two conv_f43_k launches — and of c11, which
+    // conv_first_k can write either way — allocated on first use as ring-layout tensors of B * C/8 eight-channel images of width W + 6 (so the
     // debug mode's ring / guard checks cover them unchanged).  A twin and its NHWC original never mix: each keeps its own zero ring.
     Tens q11, q1, q21, q2, q31, q32, q33;
 };
@@ -454,7 +454,7 @@ hipError_t f43_attr() { return hipFuncSetAttribute((const void*)conv_f43_k<EPI, 
 #define FK(EPI) {32, 9, 0, EPI, &f43_launch<EPI>, "conv_f43<" #EPI ">", &f43_attr<EPI>, nullptr}
 // the same kernels on channel-chunk-major tensors (conv_f43.h LAY: bit 0 input, bit 1 output): the instantiations the per-frame path uses
 struct F43LayKey { int EPI, LAY; ConvFn fn; const char* name; AttrFn attr; };
-#define FKL(EPI, LAY) {EPI, LAY, &f43_launch<EPI, LAY>, "conv_f43<" #EPI ">", &f43_attr<EPI, LAY>}
+#define FKL(EPI, LAY) {EPI, LAY, &f43_launch<EPI, LAY>, "conv_f43<" #EPI ", " #LAY ">", &f43_attr<EPI, LAY>}
 // F(4x4,3x3): the same-resolution 3x3 layers of the per-frame path with Cin, Cout >= 64, when the launch carries enough
 // frames (conv()).  3-6x the rounding error of F(2x2,3x3) and 1.13-1.22x its rate at 8 frames per launch.
 #define WK(EPI) {32, 9, 0, EPI, &wsplit_launch<EPI, 0>, "conv_wino<" #EPI ">", &wsplit_attr<EPI, 0>, nullptr}
@@ -551,15 +551,16 @@ int conv(rrv_handle h, const ConvCall& c) {
     }
     const int lay = (c.in_p8 ? 1 : 0) | (c.out_p8 ? 2 : 0);
     ConvFn lay_fn = nullptr;
+    const char* lay_name = nullptr;
     const bool ups_p8 = lay == 2 && c.ups;      // the upsample-fused kernel writes a P8 tensor through ConvP::out_p8 (no separate instantiation)
     if (lay && !ups_p8) {
         if (!f43) return fail(h, RRV_E_ARG, "conv: channel-chunk-major tensors are conv_f43_k's");
         for (const F43LayKey& e : F43_LAY_TABLE)
-            if (e.EPI == c.epi && e.LAY == lay) lay_fn = e.fn;
+            if (e.EPI == c.epi && e.LAY == lay) { lay_fn = e.fn; lay_name = e.name; }
         if (!lay_fn) return fail(h, RRV_E_ARG, "conv: no conv_f43_k instantiation for this layout");
     }
     ConvP p{};
-    p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W; p.Cin = w.Cin;
+    p.in = c.in->p; p.Hi = c.in->H; p.Wi = c.in->W - (c.in_p8 ? 6 : 0); p.Cin = w.Cin;
     p.out = c.out->p; p.H = c.H; p.W = c.W; p.Cout = w.Cout; p.B = c.B;
     p.in_bstride0 = 1;
     p.wpk = f43 ? w.pk_f43 : wino ? (c.ups ? (fuse_sc ? w.pk_ups_sc : w.pk_ups) : w.pk_wino) : w.pk; p.bias = w.bias;
@@ -580,9 +581,9 @@ int conv(rrv_handle h, const ConvCall& c) {
     if ((c.in_p8 ? c.in->C != 8 || c.in->B < c.B * (w.Cin / 8) : c.in->C != w.Cin) ||
         (c.out_p8 ? c.out->C != 8 || c.out->B < c.B * (w.Cout / 8) : c.out->C != w.Cout * ks)) return fail(h, RRV_E_ARG, "conv: channel mismatch");
     const int eh = c.ups ? c.H / 2 : c.H, ew = c.ups ? c.W / 2 : c.W;
-    if (c.in->H != eh || c.in->W != ew) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");
+    if (c.in->H != eh || c.in->W != ew + (c.in_p8 ? 6 : 0)) return fail(h, RRV_E_ARG, "conv: input geometry mismatch");      // (a P8 twin is 6 pixels wider: conv_f43.h P8_PAD)
     const int oh = (c.epi & E_POOL) ? c.H / 2 : c.H, ow = (c.epi & E_POOL) ? c.W / 2 : c.W;
-    if (c.out->H != oh || c.out->W != ow) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
+    if (c.out->H != oh || c.out->W != ow + (c.out_p8 ? 6 : 0)) return fail(h, RRV_E_ARG, "conv: output geometry mismatch");
     const int TS = f43 ? 32 : 16;                        // pixel tile edge of a work item
     if (wino) { p.tiles_x = (c.W + TS - 1) / TS; p.tiles_y = (c.H + TS - 1) / TS; }
     double win_frac = 1.0;
@@ -620,10 +621,10 @@ int conv(rrv_handle h, const ConvCall& c) {
     }
     if (h->profiling) {   // "<kernel>@CinxCout@HxW": bench.py groups by the part before '@'
         char nm[160];
-        snprintf(nm, sizeof nm, "%s@%dx%d@%dx%d", k->name, w.Cin, w.Cout, c.H, c.W);
+        snprintf(nm, sizeof nm, "%s@%dx%d@%dx%d", lay_name ? lay_name : k->name, w.Cin, w.Cout, c.H, c.W);
         return launch(h, nm, flops, bytes, [&] { fn(p, grid, s); }, flops_exec);
     }
-    return launch(h, k->name, flops, bytes, [&] { fn(p, grid, s); }, flops_exec);
+    return launch(h, lay_name ? lay_name : k->name, flops, bytes, [&] { fn(p, grid, s); }, flops_exec);
 }
 
 // ---- weights ----------------------------------------------------------------------------
@@ -890,13 +891,13 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
     if (p8 && !e.q33.p) {      // first use of this plan with the chain: the twins, for as many images as the plan holds
         const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
         auto build = [&]() -> int {
-            RCHK(talloc(h, &e.q11, e.B * 8, H, W, 8));
-            RCHK(talloc(h, &e.q1, e.B * 8, H2, W2, 8));
-            RCHK(talloc(h, &e.q21, e.B * 16, H2, W2, 8));
-            RCHK(talloc(h, &e.q2, e.B * 16, H4, W4, 8));
-            RCHK(talloc(h, &e.q31, e.B * 32, H4, W4, 8));
-            RCHK(talloc(h, &e.q32, e.B * 32, H4, W4, 8));
-            RCHK(talloc(h, &e.q33, e.B * 32, H4, W4, 8));
+            RCHK(talloc(h, &e.q11, e.B * 8, H, W + 6, 8));
+            RCHK(talloc(h, &e.q1, e.B * 8, H2, W2 + 6, 8));
+            RCHK(talloc(h, &e.q21, e.B * 16, H2, W2 + 6, 8));
+            RCHK(talloc(h, &e.q2, e.B * 16, H4, W4 + 6, 8));
+            RCHK(talloc(h, &e.q31, e.B * 32, H4, W4 + 6, 8));
+            RCHK(talloc(h, &e.q32, e.B * 32, H4, W4 + 6, 8));
+            RCHK(talloc(h, &e.q33, e.B * 32, H4, W4 + 6, 8));
             return RRV_OK;
         };
         const int rc = build();
@@ -1026,7 +1027,7 @@ int resblock_frame(rrv_handle h, int B, const char* blk, const Tens& in, Tens& x
     if (qa && (h->p8 & 2)) {
         const ConvW& w2 = h->conv[p + ".conv2"];
         p8 = use_f43(h, w2, B, a.H, a.W, E_LRELU | E_NORM1 | E_RES_UPS | E_NORM2, false, 0, false) && !(wo && ((wo->y0 | wo->x0 | wo->y1 | wo->x1) & 31));
-        if (p8 && (!qa->p || qa->B < a.B * (a.C / 8))) RCHK(talloc(h, qa, a.B * (a.C / 8), a.H, a.W, 8));
+        if (p8 && (!qa->p || qa->B < a.B * (a.C / 8))) RCHK(talloc(h, qa, a.B * (a.C / 8), a.H, a.W + 6, 8));
         if (p8) a_in = qa;
     }
     // conv1 behind the upsample and, in the same kernel, the 1x1 shortcut at the input resolution: up(conv1x1(x)) == conv1x1(up(x))

@@ -2,7 +2,7 @@
 // conv_wino_split_k (F(2x2,3x3)) on the layers / epilogues of the per-frame path where the library chooses between them.
 // No kernel lives here: ablations are the library header compiled with -DF43_ABL=n (one binary per value, see
 // tools/f43_ablations.sh); F43_ABL & 16 prints the per-phase clock64 timeline instead of rates.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DF43_ABL=n] tools/f43_bench.hip -o tools/bin/f43_bench[_n]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DF43_ABL=n] [-DF43_LAY=l] [-DF43_SPAN=s] tools/f43_bench.hip -o tools/bin/f43_bench[_n]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,17 +25,20 @@ static dim3 grid_for(ConvP& p, int tile) {
     return grid;
 }
 
+#ifndef F43_LAY
+#define F43_LAY 0      // tensor layouts of the conv_f43_k under test (conv_f43.h LAY: 1 channel-chunk-major input, 2 output; the buffers are the same, timing only)
+#endif
 template <int EPI>
 float run43(ConvP p, int iters, long long* dbg = nullptr) {
     p.dbg = dbg;
     dim3 grid = grid_for(p, 32);
-    CK(hipFuncSetAttribute((const void*)conv_f43_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F43Geo::SMEM));
+    CK(hipFuncSetAttribute((const void*)conv_f43_k<EPI, F43_LAY>, hipFuncAttributeMaxDynamicSharedMemorySize, F43Geo::SMEM));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((conv_f43_k<EPI>), grid, dim3(256), F43Geo::SMEM, 0, p);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((conv_f43_k<EPI, F43_LAY>), grid, dim3(256), F43Geo::SMEM, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_f43_k<EPI>), grid, dim3(256), F43Geo::SMEM, 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_f43_k<EPI, F43_LAY>), grid, dim3(256), F43Geo::SMEM, 0, p);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -64,8 +67,8 @@ template <int EPI>
 static void bench(const char* name, int B, int H, int W, int Cin, int Cout) {
     const bool pool = EPI & E_POOL;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
-    const size_t in_f = (size_t)B * (H + 2) * (W + 2) * Cin + (size_t)48 * (W + 50) * Cin;
-    const size_t out_f = (size_t)B * (Ho + 2) * (Wo + 2) * Cout + (size_t)48 * (W + 50) * Cout;
+    const size_t in_f = (size_t)B * (H + 2) * (W + 2 + P8_PAD) * Cin + (size_t)48 * (W + 50) * Cin;      // (room for the wider rows of a channel-chunk-major interpretation, F43_LAY)
+    const size_t out_f = (size_t)B * (Ho + 2) * (Wo + 2 + P8_PAD) * Cout + (size_t)48 * (W + 50) * Cout;
     const size_t res_f = (size_t)B * (H / 2 + 2) * (W / 2 + 2) * Cout + 4096;
     float *in, *out, *w43, *w23, *wraw, *bias, *n1, *sty, *res;
     CK(hipMalloc(&in, in_f * 4)); CK(hipMalloc(&out, out_f * 4)); CK(hipMalloc(&res, res_f * 4));
