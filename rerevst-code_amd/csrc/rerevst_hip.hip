@@ -516,7 +516,11 @@ bool use_f43(rrv_handle h, const ConvW& w, int B, int H, int W, int epi, bool up
     const double items43 = (double)((H + 31) / 32) * ((W + 31) / 32) * B * slabs, items23 = (double)((H + 15) / 16) * ((W + 15) / 16) * B * slabs;
     const int ci = w.Cin >= 256 ? 2 : (w.Cin >= 128 ? 1 : 0);
     static const double BASE_POOL[3] = {1.33, 1.38, 1.41}, BASE_RELU[3] = {1.29, 1.35, 1.39}, BASE_RES[3] = {1.26, 1.33, 1.38};      // round 5 (profiles/r05_f43_timeline.txt, F43_DMA=6)
-    const double base = (epi & E_POOL) ? BASE_POOL[ci] : (epi & E_RES_UPS) ? BASE_RES[ci] : BASE_RELU[ci];
+    // round 6: with its input channel-chunk-major conv_f43_k is 12 % faster (run_encoder / resblock_frame feed it that way whenever the
+    // consumer runs conv_f43_k; the ReLU layers also WRITE it, 32-byte pieces: profiles/r06_f43_layout.txt, tools/f43_bench.hip -DF43_LAY=1 / 3)
+    static const double P8_POOL[3] = {1.47, 1.53, 1.56}, P8_RELU[3] = {1.36, 1.44, 1.52}, P8_RES[3] = {1.41, 1.48, 1.53};
+    const bool p8 = (h->p8 & (w.f43_bit < 7 ? 1 : 2)) != 0;
+    const double base = (epi & E_POOL) ? (p8 ? P8_POOL : BASE_POOL)[ci] : (epi & E_RES_UPS) ? (p8 ? P8_RES : BASE_RES)[ci] : (p8 ? P8_RELU : BASE_RELU)[ci];
     return rounds(items23) >= 1.04 * rounds(items43) * 4.0 / base;
 }
 

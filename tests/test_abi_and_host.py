@@ -242,11 +242,11 @@ def test_tools_hold_no_copies_of_the_library_kernels():
 @pytest.mark.parametrize("cfg", ["256", "512", "1024", "ms4"])
 def test_pmc_read_traffic_is_not_below_the_compulsory_input(cfg):
     """profiles/hbm_traffic_<cfg>.json turns rocprofv3's FETCH_SIZE into bytes with a per-kernel factor F (the counter tallies
-    64 B per L2 request whatever its width: tools/pmc_traffic_json.py, profiles/r05_fetch_calib.txt).  A wrong factor shows up
+    64 B per L2 request whatever its width: tools/pmc_traffic_json.py, profiles/r05_fetch_calib.txt, r06_fetch_calib.txt).  A wrong factor shows up
     as a kernel that "reads" less than it must (round 4: conv_f43_k at F = 0.5 reported half its input).  For every kernel whose
     compulsory read per launch is far beyond what the caches can hold (>= 256 MB: 32 MB of L2, and the producer's output of
     the previous launch cannot all sit in the memory-side cache) the read bytes must reach 0.8 x that compulsory read = the
-    algorithmic bytes of the same configuration's bench line (profiles/r05_bench_<cfg>.json: input + output + residual +
+    algorithmic bytes of the same configuration's bench line (profiles/r06_bench_<cfg>.json: input + output + residual +
     weights, each once) minus the bytes it measurably wrote.  (Measured: 0.83 - 1.56; the 128-byte residual rows of
     conv_f43_k<54> and what still sits in the caches account for the values below 1.)"""
     import json
@@ -257,7 +257,7 @@ def test_pmc_read_traffic_is_not_below_the_compulsory_input(cfg):
     spec.loader.exec_module(bench)
     with open(os.path.join(root, "profiles", "hbm_traffic_%s.json" % cfg)) as f:
         traffic = json.load(f)["kernels"]
-    with open(os.path.join(root, "profiles", "r05_bench_%s.json" % cfg)) as f:
+    with open(os.path.join(root, "profiles", "r06_bench_%s.json" % cfg)) as f:
         line = json.loads(f.read().strip().splitlines()[-1])
     checked = 0
     for row in line["kernels"]:

@@ -66,6 +66,28 @@ __global__ __launch_bounds__(256) void chunkmajor_k(const char* __restrict__ in,
     if (((const float*)lds)[threadIdx.x] == 123.456f) out[0] = 1.f;
 }
 
+// conv_f43_k's requests into a channel-chunk-major plane (round 6, conv_f43.h LAY & 1): a tile's halo = 34 rows x 36 pixels x 32 bytes, the rows
+// 1 152 contiguous bytes one plane row (648 pixels = 20 736 bytes) apart; lane order as the kernel's asrc[]: (16-byte half, column group of 4, column
+// phase, row).  The tiles partition the planes, so every byte is read exactly once.
+__global__ __launch_bounds__(256) void p8row_k(const char* __restrict__ in, float* out, size_t ntiles) {
+    __shared__ __attribute__((aligned(16))) char lds[4096];
+    constexpr int PITCH = 648, RAW_PIECES = 34 * 4 * 9 * 2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = threadIdx.x;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const size_t trow = t / 18, tcol = t % 18;
+        const char* base = in + (trow * 34 * PITCH + tcol * 36) * 32;
+        for (int it = 0; it < 10; ++it) {
+            int e = it * 256 + tid;
+            if (e >= RAW_PIECES) continue;
+            const int half = e & 1, xd = (e >> 1) % 9, ph = ((e >> 1) / 9) & 3, y = (e >> 1) / 36;
+            bufld16(base, lds + wave * 1024, ((y * PITCH + 4 * xd + ph) * 8 + 4 * half) * 4, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+    if (((const float*)lds)[threadIdx.x] == 123.456f) out[0] = 1.f;
+}
+
 template <int C>
 void run_chunkmajor(const char* buf, float* out, size_t bytes) {
     const size_t nblocks = bytes / ((size_t)1024 * C * 4);
@@ -101,5 +123,11 @@ int main() {
     run_chunkmajor<64>(buf, out, bytes);
     run_chunkmajor<128>(buf, out, bytes);
     run_chunkmajor<256>(buf, out, bytes);
+    {
+        const size_t ntiles = bytes / ((size_t)34 * 648 * 32) * 18;
+        hipLaunchKernelGGL(p8row_k, dim3(256), dim3(256), 0, 0, buf, out, ntiles);
+        CK(hipDeviceSynchronize());
+        printf("p8row_k: %zu tiles, %zu useful bytes\n", ntiles, ntiles * 34 * 36 * 32);
+    }
     return 0;
 }

@@ -13,6 +13,8 @@ BYTES = 2 << 30
 def useful(name):
     if name.startswith("stream_k"):
         return BYTES
+    if name.startswith("p8row_k"):
+        return BYTES // (34 * 648 * 32) * 18 * 34 * 36 * 32      # whole 34-row bands of eighteen 36-pixel tiles
     if "chunkmajor_k" in name:
         return BYTES          # every byte once (2 GiB is a whole number of 1024-pixel blocks for 64 / 128 / 256 channels)
     m = re.search(r"seg_k<(\d+), (\d+)>", name)

@@ -9,10 +9,12 @@ once from a 2 GiB buffer):
     64-byte segments (the transform-domain kernels' LDS-DMA: 16 channels of a pixel)   FETCH_SIZE = 1.0 x bytes  ->  F = 1
     sparse 32-byte segments                                                            FETCH_SIZE = 2.0 x bytes  ->  F = 0.5
     conv_f43_k: every 32-byte piece of each line, chunk-major (r05_fetch_calib.txt)    FETCH_SIZE = 1.08-1.56 x   ->  F = 1 (upper bound)
+    conv_f43_k<.., LAY & 1>: rows of a channel-chunk-major plane (r06_fetch_calib.txt)   FETCH_SIZE = 0.5 x bytes  ->  F = 2
 (rounds 1-2 applied F = 2 to every kernel, which doubled the read side of the Winograd kernels: the "1.46x traffic" of
 the dominant kernel was this artefact — with F = 1 it reads 1.27x its input (halo rows) and moves 1.09x its algorithmic bytes.)
 bench.py reads this file to fill roofline.traffic for its dominant kernel (PMC counters cannot be collected inside the timed run)."""
 import json
+import re
 import sqlite3
 import sys
 from collections import defaultdict
@@ -31,6 +33,11 @@ def per_kernel(path, counter):
 
 def fetch_factor(name):
     """Bytes per FETCH_SIZE byte for the kernel's read pattern (see the module docstring)."""
+    m = re.match(r"void conv_f43_k<\d+, (\d+)>", name)
+    if m and int(m.group(1)) & 1:
+        # channel-chunk-major input (round 6, conv_f43.h LAY & 1): a halo row is 1 152 contiguous bytes, the L2 fetches whole 128-byte lines.
+        # Calibrated on that pattern (tools/fetch_calib.hip p8row_k, profiles/r06_fetch_calib.txt): FETCH_SIZE = 0.500 x the bytes.
+        return 2.0
     if name.startswith("void conv_f43_k"):
         # 8-channel chunks: 32-byte pieces of every pixel, chunk after chunk over the same 128-byte lines.  Calibrated on that
         # pattern (tools/fetch_calib.hip chunkmajor_k, profiles/r05_fetch_calib.txt): FETCH_SIZE = 1.56 / 1.11 / 1.08 x the bytes
@@ -47,8 +54,8 @@ def main(fetch_db, write_db, cmd):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     out = {"source": {"fetch": fetch_db, "write": write_db, "command": cmd,
                       "formula": "bytes = (F*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, averaged over launches; F = 1 for the 64-byte-segment "
-                                 "LDS-DMA kernels and for conv_f43_k (upper bound: its pattern calibrates to 0.64-0.93), 2 for >= 128-byte "
-                                 "contiguous reads (profiles/r05_fetch_calib.txt)"},
+                                 "LDS-DMA kernels and for conv_f43_k on NHWC input (upper bound: its pattern calibrates to 0.64-0.93), 2 for >= 128-byte "
+                                 "contiguous reads incl. conv_f43_k on channel-chunk-major input (profiles/r05_fetch_calib.txt, r06_fetch_calib.txt)"},
            "kernels": {}}
     for n in sorted(set(f) | set(w)):
         fb = fetch_factor(n) * f.get(n, (0, 0))[0] * 1024
