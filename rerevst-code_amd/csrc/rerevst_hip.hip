@@ -185,6 +185,7 @@ struct rrv_ctx {
     int f43_mode = 1;                 // rrv_set_f43 / RRV_F43: layers with an F(4x4,3x3) pack run on conv_f43_k — 0 never, 1 where the launch has enough work items for it to win (use_f43), 2 always
     unsigned f43_layers = F43_DEFAULT_LAYERS;   // which of the packed layers may run on conv_f43_k (RRV_F43_LAYERS overrides: experiments / parity attribution)
     bool illcond = false;             // some computed style's state is ill-conditioned (StyleState::illcond)
+    bool enc_p8_tables = false;       // use_f43 prices the encoder layers with conv_f43_k's P8-input ratios (set by run_encoder while it decides / runs a P8 chain)
     int p8 = 3;                       // channel-chunk-major tensors in front of conv_f43_k launches (conv_f43.h LAY): bit 0 the encoder chain (EncPlan::q11 ..), bit 1 ResidualBlock.conv2's input (DecPlan::qa4 ..); RRV_P8=0: NHWC everywhere (A/B, same bits)
     bool f43_path = false;            // true inside transfer_device only: the preparation pass (prepare_style / add / compute, frame mode) always runs F(2x2,3x3)
     unsigned direct_layers = 0;       // RRV_DIRECT_LAYERS: encoder convs (bit i = vgg conv i: 1 conv1_2 .. 8 conv4_1) of the per-frame path that run the direct-form kernel
@@ -519,7 +520,7 @@ bool use_f43(rrv_handle h, const ConvW& w, int B, int H, int W, int epi, bool up
     // round 6: with its input channel-chunk-major conv_f43_k is 12 % faster (run_encoder / resblock_frame feed it that way whenever the
     // consumer runs conv_f43_k; the ReLU layers also WRITE it, 32-byte pieces: profiles/r06_f43_layout.txt, tools/f43_bench.hip -DF43_LAY=1 / 3)
     static const double P8_POOL[3] = {1.47, 1.53, 1.56}, P8_RELU[3] = {1.36, 1.44, 1.52}, P8_RES[3] = {1.41, 1.48, 1.53};
-    const bool p8 = (h->p8 & (w.f43_bit < 7 ? 1 : 2)) != 0;
+    const bool p8 = w.f43_bit < 7 ? h->enc_p8_tables : (h->p8 & 2) != 0;      // (the encoder chain is P8 only as a whole: run_encoder asks with the P8 ratios first and falls back to the NHWC ones)
     const double base = (epi & E_POOL) ? (p8 ? P8_POOL : BASE_POOL)[ci] : (epi & E_RES_UPS) ? (p8 ? P8_RES : BASE_RES)[ci] : (p8 ? P8_RELU : BASE_RELU)[ci];
     return rounds(items23) >= 1.04 * rounds(items43) * 4.0 / base;
 }
@@ -887,10 +888,13 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
     // of use_f43 says yes for every launch with enough work items: the batched entries); any other mix keeps NHWC throughout.  The
     // choice changes no bit of the result — conv_f43_k stages the same bytes from either layout.
     bool p8 = which == 0 && h->f43_path && (h->p8 & 1);
+    struct TablesScope { rrv_handle h; ~TablesScope() { h->enc_p8_tables = false; } } tables_scope{h};
     {
         const int lh[8] = {0, H, H / 2, H / 2, H / 4, H / 4, H / 4, H / 4}, lw[8] = {0, W, W / 2, W / 2, W / 4, W / 4, W / 4, W / 4};
         const int le[8] = {0, E_RELU | E_POOL, E_RELU, E_RELU | E_POOL, E_RELU, E_RELU, E_RELU, E_RELU | E_POOL};
+        h->enc_p8_tables = p8;      // priced as a P8 chain first; if one layer then prefers F(2x2,3x3) the chain is NHWC and every layer is priced again as such (in conv())
         for (int i = 1; i <= 7 && p8; ++i) p8 = !D_(i) && use_f43(h, *W_(i), B, lh[i], lw[i], le[i], false, 0, false);
+        h->enc_p8_tables = p8;
     }
     if (p8 && !e.q33.p) {      // first use of this plan with the chain: the twins, for as many images as the plan holds
         const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;

@@ -191,3 +191,45 @@ def dec4_subsets(n_inputs=32):
 
 if "--dec4-subsets" in sys.argv:
     dec4_subsets()
+
+
+def guard_case(n_inputs=32):
+    """the conditioning guard of use_f43 (dynamic filters above 4 sqrt(32) = 22.6 in Frobenius norm keep the encoder on F(2x2,3x3))
+    was fitted to two populations — every seeded / real state at 5.5 .. 5.8 and the x4-decoder set at 2e2 .. 3e6.  In between: every decoder
+    weight x 2 (`dec2`; no reference golden exists for it, so its state is the CPU oracle's, computed from global_a's inputs).  Filter norms,
+    which side of the guard the library puts it on, and the margin distribution with conv_f43_k on all ten layers / F(2x2,3x3) everywhere /
+    the default rule at sixteen frames per launch."""
+    w = pkg.weight_variant("dec2")
+    g = T.load_golden("global_a")
+    style, frames, ids, tid = T.golden_inputs(pkg, g)
+    o = O.Stylization(w)
+    o.prepare_style(style); o.clean()
+    for i in ids: o.add(frames[i])
+    o.compute()
+    state = o.get_state()
+    o0 = 4 * sum(T.NORM_CH)
+    norms = [float(np.sqrt((state[o0 + 1024 * f:o0 + 1024 * (f + 1)].astype(np.float64) ** 2).sum())) for f in range(6)]
+    print("\n# dec2 (every decoder weight x 2), state from the CPU oracle: dynamic-filter Frobenius norms %s against the guard %.1f" % (", ".join("%.1f" % n for n in norms), 4 * np.sqrt(32.0)))
+    hip = pkg.Stylization(w, cuda=True)
+    hip.set_state(state)
+    rows = {"oracle": [], 0: [], 2: [], 1: []}
+    for i in range(n_inputs):
+        f = O.reflect_pad(pkg.synth_frame(5000 + i, 128, 128, kind="noise" if i & 1 else "smooth", seed=200 + i), 256, 256)
+        O.set_conv_backend("torch64")
+        try:
+            ref = o.transfer(f, return_preclamp=True)[0]
+        finally:
+            O.set_conv_backend("numpy")
+        rows["oracle"].append(T.pre_worst(o.transfer(f, return_preclamp=True)[0], ref)[0])
+        for mode, nb in ((0, 1), (2, 4), (1, 16)):
+            hip.set_f43(mode)
+            hip.transfer_batch([f] * nb)
+            rows[mode].append(T.pre_worst(hip.preclamp(256, 256), ref)[0])
+    hip.close()
+    for key, tag in (("oracle", "the float32 oracle itself (numpy GEMMs)"), (0, "HIP, F(2x2,3x3) everywhere"), (2, "HIP, conv_f43_k on all ten packed layers"), (1, "HIP, default rule, 16 per launch")):
+        r = np.array(rows[key])
+        print("dec2   %-42s pre-clamp worst/bound: max %.3f, 99th pct %.3f, median %.3f, inputs over 0.8: %2d" % (tag, r.max(), np.percentile(r, 99), np.median(r), int((r > 0.8).sum())), flush=True)
+
+
+if "--guard-case" in sys.argv:
+    guard_case()
