@@ -51,16 +51,30 @@ def fixed_kernels(*handles, mode=0):
 # F(4x4,3x3) — the two differ by the kernels' rounding (<= 0.03 grey levels, inside the parity bound of 0.05), not by a defect.
 _F43_MODE2_SKIPS = ("test_config5_full_size_1024_four_styles_vs_oracle", "test_multistyle_batched_transfer_equals_per_frame",
                     "test_random_sequence_of_multistyle_entries_is_bit_exact", "test_multistyle_feature_api_matches_reference",
-                    "test_real_multistyle_matches_reference")
+                    "test_real_multistyle_matches_reference",
+                    # round 6: the one-frame caching entry is F(2x2,3x3) in every mode, the batched one follows the mode
+                    "test_batched_feature_caching_equals_per_frame", "test_multistyle_command_line_driver_end_to_end")
+# a suite forced onto ONE family cannot show that the DEFAULT picks another one per launch / per conditioning
+_FORCED_FAMILY_SKIPS = ("test_ill_conditioned_state_keeps_f43_off_the_encoder",)
+
+
+def forced_family():
+    """RRV_F43=0 / 2 in the environment: the whole suite runs on one kernel family (tests then drop the assertions that the
+    default choice differs from a pinned family)."""
+    return os.environ.get("RRV_F43") in ("0", "2")
 
 
 def pytest_collection_modifyitems(config, items):
-    if os.environ.get("RRV_F43") != "2":
+    if not forced_family():
         return
-    skip = pytest.mark.skip(reason="multi-style cross-entry comparison: cached features and per-image-state kernels are F(2x2,3x3) in every mode")
+    skip2 = pytest.mark.skip(reason="multi-style cross-entry comparison: cached features and per-image-state kernels are F(2x2,3x3) in every mode")
+    skipf = pytest.mark.skip(reason="needs the default kernel choice (RRV_F43 forces one family)")
     for it in items:
-        if it.name.split("[")[0] in _F43_MODE2_SKIPS:
-            it.add_marker(skip)
+        name = it.name.split("[")[0]
+        if os.environ.get("RRV_F43") == "2" and name in _F43_MODE2_SKIPS:
+            it.add_marker(skip2)
+        if name in _FORCED_FAMILY_SKIPS:
+            it.add_marker(skipf)
 
 
 def pytest_configure(config):

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (load_golden, golden_inputs, assert_state_close, assert_pre_close, pre_full_size, img_full_size, IMG_ATOL, fixed_kernels)
+from conftest import (load_golden, golden_inputs, assert_state_close, assert_pre_close, pre_full_size, img_full_size, IMG_ATOL, fixed_kernels, forced_family)
 
 pytestmark = pytest.mark.gpu
 
@@ -87,7 +87,7 @@ def test_config5_full_size_1024_four_styles_vs_oracle(pkg, weights, oracle):
     pre = s.preclamp(1152, 1152, image=1)                 # the launch's second image: frame 0 with all four styles
     with fixed_kernels(s):
         pinned = np.array(s.transfer_many([feats[1], feats[0]], wts))
-    assert not np.array_equal(pinned, many)               # the default really ran conv_f43_k here
+    assert forced_family() or not np.array_equal(pinned, many)               # the default really ran conv_f43_k here
     o = oracle.MultiStylization(weights, S)
     for k in range(S):
         o.per_style[k].set_state(s.get_state(k))
@@ -141,7 +141,7 @@ def test_config5_as_benched_four_white_noise_frames_per_group_vs_oracle(pkg, wei
     many = np.array(s.transfer_many(feats, wts))
     pres = {k: np.array(s.preclamp(1152, 1152, image=k)) for k in (1, 3)}
     with fixed_kernels(s):
-        assert not np.array_equal(s.transfer_many(feats, wts), many)      # the default really ran conv_f43_k in this launch shape
+        assert forced_family() or not np.array_equal(s.transfer_many(feats, wts), many)      # the default really ran conv_f43_k in this launch shape
     np.testing.assert_array_equal(s.transfer_many(feats, wts), many)      # run-to-run determinism
     o = oracle.MultiStylization(weights, S)
     for k in range(S):

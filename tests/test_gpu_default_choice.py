@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from conftest import load_golden, pre_full_size, img_full_size, IMG_ATOL, fixed_kernels
+from conftest import load_golden, pre_full_size, img_full_size, IMG_ATOL, fixed_kernels, forced_family
 
 pytestmark = pytest.mark.gpu
 
@@ -74,7 +74,7 @@ def test_headline_sixteen_white_noise_frames_per_launch_vs_oracle(headline, pkg,
     pres = {k: np.array(s.preclamp(640, 640, image=k)) for k in (0, 7, 15)}
     with fixed_kernels(s):
         pinned = np.array(s.transfer_batch(frames))
-    assert not np.array_equal(pinned, out)                  # the default really chose other kernels than F(2x2,3x3) everywhere
+    assert forced_family() or not np.array_equal(pinned, out)                  # the default really chose other kernels than F(2x2,3x3) everywhere
     with fixed_kernels(s, mode=2):
         np.testing.assert_array_equal(s.transfer_batch(frames), out)      # ... namely conv_f43_k on every packed layer
     for k in (0, 7, 15):
@@ -115,7 +115,7 @@ def test_config2_thirty_two_frames_per_launch_vs_oracle(pkg, weights, oracle, vi
     out = np.array(s.transfer_batch(frames))
     pres = {k: np.array(s.preclamp(384, 384, image=k)) for k in (0, 12, 30)}
     with fixed_kernels(s):
-        assert not np.array_equal(s.transfer_batch(frames), out)
+        assert forced_family() or not np.array_equal(s.transfer_batch(frames), out)
     for k in range(0, 32, 6):            # every sixth frame of the launch (a frame's arithmetic does not depend on its place in it)
         if k in pres:
             ref = _pre_check(oracle, o, frames[k], pres[k], "config 2 frame %d of 32, default kernel choice, pre-clamp" % k)
@@ -143,7 +143,7 @@ def test_1024_single_style_four_frames_per_launch_vs_oracle(pkg, weights, oracle
     out = np.array(s.transfer_batch(frames))
     pres = {k: np.array(s.preclamp(1152, 1152, image=k)) for k in (0, 3)}
     with fixed_kernels(s):
-        assert not np.array_equal(s.transfer_batch(frames), out)         # four 1152 x 1152 frames per launch: the rule picks conv_f43_k
+        assert forced_family() or not np.array_equal(s.transfer_batch(frames), out)         # four 1152 x 1152 frames per launch: the rule picks conv_f43_k
     np.testing.assert_array_equal(s.transfer_batch(frames), out)
     for k in (0, 3):
         ref = _pre_check(oracle, o, frames[k], pres[k], "1024 x 1024 frame %d of 4, default kernel choice, pre-clamp" % k)
