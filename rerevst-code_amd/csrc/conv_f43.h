@@ -22,7 +22,10 @@
 //  * the four waves of a workgroup share one U block (36 x 32 couts x 8 channels = 36 KB) and one 34 x 34 halo
 //    (40 KB), both double buffered by buffer_load ... lds: 154 KB of LDS, one workgroup per CU;
 //  * a work item = 32 x 32 output pixels x 32 output channels; persistent workgroups walk the items as one stream
-//    (the last two chunks of an item request the next item's first tiles, as in conv_wino_k).
+//    (the last two chunks of an item request the next item's first tiles, as in conv_wino_k);
+//  * 8-channel chunks mean 32-byte pieces of an NHWC pixel: the halo of a chunk is 2 312 of them, 32 cache lines per 1 KB LDS-DMA
+//    request, and the L2 -> LDS path charges per line — so between two launches of this kernel the activations travel
+//    channel-chunk-major (template parameter LAY below, round 6: +12 %).
 //
 // LDS images (conflict free in every lane group the LDS serves in one cycle):
 //  raw : [halo row y 0..33][x & 3][x >> 2 (0..8)][32 B = 4 slots of one channel pair]; slot = pair ^ 2*((y>>2)&1):
