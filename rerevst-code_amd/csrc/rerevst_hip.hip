@@ -885,8 +885,9 @@ int run_encoder(rrv_handle h, EncPlan& e, const uint8_t* d_img, int which, const
     };
     auto D_ = [&](int i) { return which == 0 && h->f43_path && ((h->direct_layers >> i) & 1u) != 0; };
     // Channel-chunk-major tensors (conv_f43.h LAY) between the seven packed layers when ALL of them run conv_f43_k in this launch (the rule
-    // of use_f43 says yes for every launch with enough work items: the batched entries); any other mix keeps NHWC throughout.  The
-    // choice changes no bit of the result — conv_f43_k stages the same bytes from either layout.
+    // of use_f43 says yes for every launch with enough work items: the batched entries); any other mix keeps NHWC throughout.  Where every
+    // level is a multiple of 32 pixels wide the choice changes no bit of the result (conv_f43_k stages the same bytes from either layout);
+    // elsewhere the edge tiles see other discarded columns (conv_f43.h P8_PAD): rounding noise, GPU test.
     bool p8 = which == 0 && h->f43_path && (h->p8 & 1);
     struct TablesScope { rrv_handle h; ~TablesScope() { h->enc_p8_tables = false; } } tables_scope{h};
     {
