@@ -116,15 +116,21 @@ def pre_worst(got, ref):
 #   the reference's own arithmetic       7.40        52 (4.2e-5)        0.650      0.0236      0.0825        9 (in 1 frame)
 #     (the oracle on torch's float32 conv2d)
 #   the library, F(2x2,3x3) everywhere  15.29       142 (1.2e-4)        1.092      0.0108      0.2427       75 (3 frames)
-# So at full size the HIP path is held, per kernel family, to ABSOLUTE limits = those maxima with ~1.3x headroom — no clause
+# The same over 32 frames at 1024 x 1024 (1152 x 1152 padded, four per launch; 3.2x the values per frame, so deeper extremes:
+# profiles/r06_fullsize_tail_1024.txt) and 64 frames at 256 x 256 (384 x 384, 32 per launch; r06_fullsize_tail_256.txt):
+#   the library, default choice, 1152^2  5.22        84 (2.1e-5)        0.463      0.0149      0.0856       11 (2 frames of 32)
+#   the reference's own arithmetic       9.69       100 (2.5e-5)        0.563      0.0244      0.1207       21 (8 frames)
+#   the library, default choice, 384^2   1.61         1 (2.3e-6)        0.357      0.0136      0.0172        0
+#   the reference's own arithmetic       1.62         5 (1.1e-5)        0.455      0.0224      0.0213        0
+# So at full size the HIP path is held, per kernel family, to ABSOLUTE limits = those maxima (over the three sizes) with ~1.3x headroom — no clause
 # relative to the float32 oracle's own tail any more (the round-5 rule let the library reach ~45x where the
 # oracle sat at 15x).  The DEFAULT choice — what ships and what bench.py times — additionally keeps the stated image
-# tolerance on every value in every frame the suite tests (`strict`; 127 of the 128 frames keep it, none of the tested ones
-# is the 128th).  Small frames and every reference golden keep the every-value bounds above.
+# tolerance on every value in every frame the suite tests (`strict`; 127 of the 128 frames at 640^2, 30 of the 32 at 1152^2 and all
+# 64 at 384^2 keep it; none of the tested frames is among the three).  Small frames and every reference golden keep the every-value bounds above.
 FULL_PCT = 99.99
 FULL_LIMITS = {
     #            mean error / bound, 99.99th percentile, share of values outside the bound, worst value / bound, values beyond IMG_ATOL, image max |d|
-    "default": dict(mean=0.02, pct=0.55, over_frac=2e-5, worst=4.0, img_over=4, img_worst=0.10),
+    "default": dict(mean=0.02, pct=0.55, over_frac=3e-5, worst=6.5, img_over=15, img_worst=0.11),
     "f22":     dict(mean=0.02, pct=1.40, over_frac=1.6e-4, worst=20.0, img_over=100, img_worst=0.32),
 }
 
