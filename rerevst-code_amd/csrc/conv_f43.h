@@ -38,7 +38,7 @@
 //
 // F43_ABL (default 0; tools/f43_bench.hip builds one binary per value): microbenchmark switches — 1 no LDS-DMA after the
 // first stage, 2 no K-loop barriers, 4 no stores, 8 no input transform, 16 per-phase clock64 timeline into p.dbg, 32 no
-// epilogue, 64 halo requests over contiguous memory (what the scattered 32-byte pieces cost), 1024 the halo computed in the loader instead of fetched (the instruction mix of conv1_1 folded into conv1_2).  (The halo access pattern and the stores of a channel-chunk-major tensor were measured the same way — ABL 128 / 256 / 512 in commit f074ee2, profiles/r06_f43_layout.txt — and became the LAY template parameter below.)  The library is compiled with 0: every hook is a discarded constexpr branch.
+// epilogue, 64 halo requests over contiguous memory (what the scattered 32-byte pieces cost).  (The halo access pattern and the stores of a channel-chunk-major tensor were measured the same way — ABL 128 / 256 / 512 in commit f074ee2, profiles/r06_f43_layout.txt — and became the LAY template parameter below; ABL 1024 in commit 034c0ff priced conv1_1 folded into this kernel's loader: 23 % slower than the pair, profiles/r06_thin_fusion.txt.)  The library is compiled with 0: every hook is a discarded constexpr branch.
 #pragma once
 #include "conv_wino.h"
 
@@ -285,7 +285,6 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         const int half = e & 1, xd = (e >> 1) % 9, ph = ((e >> 1) / 9) & 3, y = (e >> 1) / 36;
         const int x = 4 * xd + ph, par = (y >> 2) & 1;
         asrc[it] = ((y * WP + x) * (INP8 ? 8 : p.Cin) + 4 * (half ^ par)) * 4;
-        if (ABL & 1024) asrc[it] = (y * 36 + x) * 4;        // microbench only: byte offset of the piece's pixel in a 36 x 36 grey tile, see the chunk tail
         if (ABL & 64) asrc[it] = (it * NT + tid) * 16;      // microbench only (wrong data): the halo requests lane-linear over 40 contiguous KB instead of 32-byte pieces one pixel stride apart
     }
     bool have = cur.b < p.B, have_nxt = false;
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
                 constexpr int step = b * 6 + r;                  // issue order of the 36 position steps of a chunk
                 auto dma_req = [&](auto nc) {                    // request n of the chunk: 0..9 the halo, 10..18 the U block
                     constexpr int n = decltype(nc)::value;
-                    if constexpr (n < G::RAW_IT) { if (!(ABL & 1024)) bufld16_rs(rs_r, rdst + (n * NT + wave * 64) * 16, asrc[n], rsoff); }
+                    if constexpr (n < G::RAW_IT) bufld16_rs(rs_r, rdst + (n * NT + wave * 64) * 16, asrc[n], rsoff);
                     else if constexpr (n < G::RAW_IT + G::U_IT) bufld16_rs(rs_u, udst + ((n - G::RAW_IT) * NT + wave * 64) * 16, tid * 16, usoff + (n - G::RAW_IT) * NT * 16);
                 };
                 {      // request n at step n * 28 / 19: the chunk's 19 requests evenly over its first 28 position steps (the CU's L2 -> LDS
@@ -449,33 +448,6 @@ __global__ __launch_bounds__(256, 1) void conv_f43_k(const ConvP p) {
         if (!last) {
             read_u_batch(ubn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
             if (!(ABL & 8)) full_transform(v);
-        }
-        if constexpr ((ABL & 1024) != 0) {
-            // Microbench only (conv1_1 folded into conv1_2's loader, priced by its INSTRUCTION MIX — the values are
-            // meaningless): instead of the ten LDS-DMA requests of a halo chunk every lane computes its ten 16-byte pieces — 4 channels
-            // of a halo pixel = ReLU(bias + 9 taps on the grey value around it) — from a 36 x 36 grey tile behind the kernel's LDS
-            // (tools/f43_bench.hip allocates it) and writes them where the DMA would have landed them: the raw buffer that is free
-            // from this barrier to the next.  9 ds_read_b32 + 18 packed FMAs + 4 max + 1 ds_write_b128 per piece; the weights
-            // come through scalar loads (uniform).
-            float wt[40];      // 9 taps x 4 channels + bias, uniform: scalar registers, loaded once per chunk
-#pragma unroll
-            for (int i = 0; i < 40; ++i) wt[i] = p.bias[i];
-            char* const fdst = smem + (1 - PAR) * RAW_BYTES;
-            const char* const grey = smem + G::SMEM;
-#pragma unroll
-            for (int it = 0; it < G::RAW_IT; ++it) {
-                if (it * NT + tid < G::RAW_PIECES) {
-                    const char* const gp = grey + asrc[it];
-                    f32x2 a0 = {wt[36], wt[37]}, a1 = {wt[38], wt[39]};
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const float g = *(const float*)(gp + (tap / 3) * 144 + (tap % 3) * 4);
-                        a0 = __builtin_elementwise_fma(f32x2{wt[tap * 4], wt[tap * 4 + 1]}, f32x2{g, g}, a0);
-                        a1 = __builtin_elementwise_fma(f32x2{wt[tap * 4 + 2], wt[tap * 4 + 3]}, f32x2{g, g}, a1);
-                    }
-                    *(f32x4*)(fdst + (it * NT + tid) * 16) = f32x4{fmaxf(a0[0], 0.f), fmaxf(a0[1], 0.f), fmaxf(a1[0], 0.f), fmaxf(a1[1], 0.f)};
-                }
-            }
         }
         tick(5);
     };

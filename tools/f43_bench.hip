@@ -32,13 +32,13 @@ template <int EPI>
 float run43(ConvP p, int iters, long long* dbg = nullptr) {
     p.dbg = dbg;
     dim3 grid = grid_for(p, 32);
-    CK(hipFuncSetAttribute((const void*)conv_f43_k<EPI, F43_LAY>, hipFuncAttributeMaxDynamicSharedMemorySize, F43Geo::SMEM + ((F43_ABL & 1024) ? 36 * 36 * 4 : 0)));
+    CK(hipFuncSetAttribute((const void*)conv_f43_k<EPI, F43_LAY>, hipFuncAttributeMaxDynamicSharedMemorySize, F43Geo::SMEM));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((conv_f43_k<EPI, F43_LAY>), grid, dim3(256), F43Geo::SMEM + ((F43_ABL & 1024) ? 36 * 36 * 4 : 0), 0, p);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((conv_f43_k<EPI, F43_LAY>), grid, dim3(256), F43Geo::SMEM, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_f43_k<EPI, F43_LAY>), grid, dim3(256), F43Geo::SMEM + ((F43_ABL & 1024) ? 36 * 36 * 4 : 0), 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_f43_k<EPI, F43_LAY>), grid, dim3(256), F43Geo::SMEM, 0, p);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
