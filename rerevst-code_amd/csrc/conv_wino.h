@@ -180,7 +180,7 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-// PERIMG = 1: per-image state (ConvP::par_bstride / bias_bstride / w_bstride), a separate instantiation as in conv_wino_split.h
+// PERIMG = 1: per-image epilogue parameters (ConvP::par_bstride; weights and bias are shared by the images of a launch), a separate instantiation as in conv_wino_split.h
 template <int EPI, int ABL = 0, int NW = 4, int UPS = 1, int SC = 0, int PERIMG = 0>
 __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_wino_k(const ConvP p) {
     static_assert(UPS == 1 && NW == 4, "library kernel: upsample-fused form, 4 waves");
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
     auto in_of = [&](const Item& a) {
         return p.in + (size_t)a.b * (size_t)(p.Hi + 2) * (p.Wi + 2) * p.Cin + (size_t)(((a.ty + p.ty0) * G::TIN) * (p.Wi + 2) + (a.tx + p.tx0) * G::TIN) * p.Cin;
     };
-    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NPU * 32 * 16) + (PERIMG ? (size_t)a.b * p.w_bstride : (size_t)0); };
+    auto w_of = [&](const Item& a) { return p.wpk + (size_t)a.nt * nchunks * (NPU * 32 * 16); };      // (PERIMG: the images of a launch share weights and bias here — only the saved statistics are per image; conv() checks)
     int asrc[G::RAW_IT];
 #pragma unroll
     for (int it = 0; it < G::RAW_IT; ++it) {
@@ -276,11 +276,11 @@ __global__ __launch_bounds__(NW * 64, (WinoGeo<NW, UPS, SC>::OCC)) void conv_win
             const int row = e >> 3, col = (e & 7) * 4;
             const float* src = p.bias;
             const int pb = PERIMG ? img * p.par_bstride : 0;
-            int off = ntile * 32 + col + (PERIMG ? img * p.bias_bstride : 0);
+            int off = ntile * 32 + col;
             if (row >= 1 && row <= 4) { src = (EPI & E_NORM1) ? p.n1 : p.bias; off = (EPI & E_NORM1) ? ntile * 32 + col + pb + (row - 1) * p.Cout : off; }
             if (row >= 5 && row <= 8) { src = (EPI & E_NORM2) ? p.n2 : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 5) * p.Cout : off; }
             if (row >= 9) { src = (EPI & E_NORM2) ? p.sty : p.bias; off = (EPI & E_NORM2) ? ntile * 32 + col + pb + (row - 9) * p.Cout : off; }
-            if (row > 10) { src = p.bias; off = ntile * 32 + (PERIMG ? img * p.bias_bstride : 0); }
+            if (row > 10) { src = p.bias; off = ntile * 32; }
             glds16(src + off, par + wave * 1024);
         }
     };

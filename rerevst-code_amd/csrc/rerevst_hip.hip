@@ -578,6 +578,7 @@ int conv(rrv_handle h, const ConvCall& c) {
     p.par_bstride = c.par_bstride; p.bias_bstride = c.bias_bstride; p.w_bstride = c.w_bstride;
     if (ups_p8) { if (!wino) return fail(h, RRV_E_ARG, "conv: no upsample-fused kernel for this layer"); p.out_p8 = 1; }
     if ((c.par_bstride | c.bias_bstride || c.w_bstride) && !wino) return fail(h, RRV_E_ARG, "conv: per-image state needs a transform-domain kernel");
+    if (c.ups && (c.bias_bstride || c.w_bstride)) return fail(h, RRV_E_ARG, "conv: the upsample-fused kernel shares weights and bias over the images of a launch");
     if (ks > 1) {       // the [1 slab][Cin/16 chunks] weight pack read as [ks slabs][Cin/16/ks chunks]: slab s = input channel slice s
         p.Cin = w.Cin / ks; p.cstride = w.Cin; p.cin_slab_step = w.Cin / ks; p.Cout = 32 * ks;
     }
